@@ -1,0 +1,164 @@
+/*
+ * gpk.h — C ABI of libgpk.so: MI355X (gfx950) kernels for the Gaussian-Process
+ * residual-model path of Grandediw/Unmanned_Aerial_Vehicles.
+ *
+ * The reference has no FFI boundary: its GP arithmetic is Python calling
+ * scikit-learn / SciPy (LAPACK) on the CPU.  Each entry point below replaces one
+ * of those CPU call sites (cited per function as <file>:<line> relative to the
+ * reference tree; `sklearn/` = scikit-learn 1.7.2, the library the reference
+ * delegates to).  The Python host side (unmanned_aerial_vehicles_amd/) binds these
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - All matrices are row-major.  "dev" pointers are device (HBM) addresses, e.g.
+ *     torch.Tensor.data_ptr() on ROCm; "host" pointers are ordinary host memory.
+ *   - Dense factor matrices are padded: Np = gpk_padded(N) = N rounded up to 128.
+ *     The Gram kernel fills the padding with the identity, so the Cholesky factor of
+ *     the padded matrix is [L 0; 0 I] and every dense kernel runs on whole tiles.
+ *   - dtype: GPK_F32 or GPK_F64 selects the element type of the void* buffers.
+ *   - Calls are asynchronous on the handle's stream unless stated otherwise;
+ *     gpk_synchronize() waits.  Functions with a host output parameter synchronise.
+ *   - Return codes: GPK_OK, GPK_NOT_PD (Cholesky pivot <= 0; 1-based row in the
+ *     error string and *info), GPK_BAD_ARG, GPK_HIP_ERROR.  gpk_last_error() gives text.
+ *   - No global state; one handle per GPU / host thread.
+ */
+#ifndef GPK_H
+#define GPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpk_context* gpk_handle;
+
+enum { GPK_F32 = 0, GPK_F64 = 1 };
+enum { GPK_OK = 0, GPK_NOT_PD = 1, GPK_BAD_ARG = 2, GPK_HIP_ERROR = 3 };
+enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_P = 16 };
+
+/* ---- context ------------------------------------------------------------------ */
+int gpk_create(gpk_handle* h, int device);
+void gpk_destroy(gpk_handle h);
+const char* gpk_last_error(gpk_handle h);
+/* stream = hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = handle's own */
+int gpk_set_stream(gpk_handle h, void* stream);
+int gpk_synchronize(gpk_handle h);
+int64_t gpk_padded(int64_t n);
+const char* gpk_version(void);
+
+/* ---- K1: RBF Gram build ---------------------------------------------------------
+ * K[i][j] = sf2 * exp(-0.5 * sum_d ((x_id - x_jd) / ls_d)^2), exact differences,
+ * diagonal = sf2 + diag_add, padding rows/cols (>= N) = identity.  Symmetric tiles are
+ * computed once and written to both halves.
+ * Replaces: sklearn/gaussian_process/kernels.py:1553-1560 (RBF.__call__, pdist + exp +
+ * squareform), :1402 (WhiteKernel diag), sklearn/gaussian_process/_gpr.py:347 (alpha
+ * jitter); quadrotor_gp_mpc/quadrotor_gp_mpc/gaussian_process.py:158-171.
+ * X: dev (N x D), ls: host double[D], K: dev (Np x ldk), ldk >= Np.                  */
+int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+             double sf2, double diag_add, void* K, int64_t ldk);
+
+/* Cross kernel, transposed layout: B[j][m] = sf2 * exp(-0.5 ||(x_j - xq_m)/ls||^2) for
+ * j < N, m < M; zero elsewhere in the (Np x Mp) padded block.  No white noise.
+ * Replaces: sklearn/gaussian_process/kernels.py:1564-1565 (cdist + exp).
+ * X dev (N x D), Xq dev (M x D), B dev (Np x ldb), ldb >= Mp = gpk_padded(M).          */
+int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t N, const void* Xq,
+                     int64_t M, int D, const double* ls, double sf2, void* B, int64_t ldb);
+
+/* ---- K2: blocked Cholesky --------------------------------------------------------
+ * In-place lower Cholesky of the padded fp64 matrix A (Np x lda): recursive blocking,
+ * 128x128 leaf factorisation in LDS, fp64-MFMA trsm/syrk/gemm tiles.  The strict upper
+ * triangle is not referenced and is left as written by gpk_gram.  winv (dev, Np x 128)
+ * receives the inverse of every 128x128 diagonal block of L (used by the solves).
+ * *info (host) = 0, or the 1-based index of the first non-positive pivot (GPK_NOT_PD).
+ * Synchronises.  Replaces: scipy.linalg.cholesky(K, lower=True) at
+ * sklearn/gaussian_process/_gpr.py:349,587; gaussian_process.py:184.                  */
+int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int* info);
+
+/* Recompute winv (inverses of the 128x128 diagonal blocks) from an existing padded factor L,
+ * e.g. one imported from a scikit-learn pickle (L_ at sklearn/gaussian_process/_gpr.py:349). */
+int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int64_t ldl, double* winv);
+
+/* Convert the lower triangle of L and winv to fp32 copies (for the fp32 predict path). */
+int gpk_factor_to_f32(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+                      float* Lf, int64_t ldlf, float* winvf);
+
+/* ---- K3: alpha = L^-T (L^-1 Y) -----------------------------------------------------
+ * Y: dev (N x P) row-major fp64 (already normalised), alpha: dev (N x P).  P <= GPK_MAX_P.
+ * Replaces: cho_solve((L, True), y) at sklearn/gaussian_process/_gpr.py:360-364,597;
+ * gaussian_process.py:187-189.                                                          */
+int gpk_potrs(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+              const double* Y, int64_t N, int P, double* alpha);
+
+/* ---- K5 building blocks: B <- L^-1 B, and column sums of squares ---------------------
+ * B: dev (Np x ldb) with Mp = multiple of 128 columns in use.  dtype selects fp32/fp64
+ * (L, winv and B must all have that dtype).
+ * Replaces: solve_triangular(L_, K_trans.T, lower=True) at sklearn/_gpr.py:454-456 and
+ * the einsum at :477.                                                                    */
+int gpk_trsm_lower_left(gpk_handle h, int dtype, const void* L, int64_t Np, int64_t ldl,
+                        const void* winv, void* B, int64_t Mp, int64_t ldb);
+/* out[m] = sum_{i < Np} B[i][m]^2, accumulated in fp64; out: dev double[Mp].              */
+int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, int64_t Mp, int64_t ldb,
+                 double* out);
+
+/* ---- K4: fused posterior mean -----------------------------------------------------------
+ * mean[m][p] = y_mean[p] + y_std[p] * sum_j k(xq_m, x_j) alpha[j][p]; K* is never stored.
+ * X dev (N x D), alpha dev (N x P), Xq dev (M x D), mean dev (M x P), all of `dtype`;
+ * ls, y_mean, y_std: host double arrays.
+ * Replaces: sklearn/gaussian_process/_gpr.py:441-447 (K_trans @ alpha_, undo normalisation);
+ * the 25-call loop at src/px4/mpc.py:1490-1506; gaussian_process.py:223-226.              */
+int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
+                     int P, const double* ls, double sf2, const double* y_mean,
+                     const double* y_std, const void* Xq, int64_t M, void* mean);
+
+/* ---- K5: posterior variance ---------------------------------------------------------------
+ * var[m] = max(kss - sum_i (L^-1 k*_m)_i^2, floor) in units of the normalised targets
+ * (caller multiplies by y_std^2).  kss = sf2 (+ noise for the sklearn surface).
+ * work: dev scratch of at least Np * Mp elements of `dtype` (Mp = gpk_padded(M)).
+ * var: dev double[Mp] (only the first M entries are meaningful).
+ * Replaces: sklearn/gaussian_process/_gpr.py:454-485; gaussian_process.py:229-232.          */
+int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+                    double sf2, const void* L, int64_t Np, int64_t ldl, const void* winv,
+                    const void* Xq, int64_t M, double kss, double floor, void* work,
+                    double* var);
+
+/* ---- K6a: log-marginal-likelihood terms -----------------------------------------------------
+ * terms[0] = sum_{i<N} log L[i][i]; terms[1 + p] = sum_i Y[i][p] * alpha[i][p]  (host doubles).
+ * Synchronises.  Replaces: sklearn/gaussian_process/_gpr.py:609-613; gaussian_process.py:250-261. */
+int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y,
+                  const double* alpha, int P, double* terms);
+
+/* ---- K6b: K^-1 and the fused LML-gradient reduction --------------------------------------------
+ * gpk_potri: Kinv (dev Np x ldk) <- lower triangle of (L L^T)^-1 (trtri + W^T W on fp64 MFMA).
+ * L is not modified.  work: dev double[Np * Np].
+ * Replaces: cho_solve((L, True), eye(N)) at sklearn/gaussian_process/_gpr.py:627-629.           */
+int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+              double* Kinv, int64_t ldk, double* work);
+/* grad[d] (d < D) = 0.5 * sum_ij Q_ij K_ij ((x_id - x_jd)/ls_d)^2, grad[D] = 0.5 * noise * tr(Q),
+ * Q = alpha alpha^T - P * Kinv, K_ij = sf2 exp(-0.5 d2_ij) recomputed on the fly (the
+ * N x N x D tensor sklearn builds at kernels.py:1576-1579 is never materialised).
+ * grad: host double[D + 2] = [g_ls_0 .. g_ls_{D-1}, g_noise, g_sf2] with g_sf2 = 0.5 * sum_ij Q_ij K_ij
+ * (the signal-variance gradient used by the package GP).  D <= 16.  Synchronises.
+ * Replaces: sklearn/gaussian_process/_gpr.py:615-647 + sklearn/gaussian_process/kernels.py:1571-1580,
+ * :1403-1408.                                                                                     */
+int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2,
+                 double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
+                 double* grad);
+
+/* ---- building block: whole-tile GEMM on the matrix cores ---------------------------------------
+ * C[m x n] = alpha * opA(A) * opB(B)^T + beta * C, m and n multiples of 128, k a multiple of 16
+ * (fp64) / 32 (fp32).  ta == 0: A stored (m x k) with k contiguous; ta == 1: A stored (k x m).
+ * tb == 0: B stored (n x k); tb == 1: B stored (k x n).  lower_only != 0 skips tiles strictly above
+ * the diagonal.  This is the kernel behind gpk_potrf / gpk_potrs / gpk_trsm_lower_left / gpk_potri;
+ * it is exported so that it can be tested and timed on its own (fp64 via v_mfma_f64_16x16x4_f64,
+ * fp32 via v_mfma_f32_32x32x2_f32).  No reference counterpart other than the BLAS-3 calls inside
+ * LAPACK's dpotrf/dtrsm (SciPy, sklearn/gaussian_process/_gpr.py:349,454).                          */
+int gpk_gemm_tiles(gpk_handle h, int dtype, int ta, int tb, const void* A, int64_t lda, const void* B,
+                   int64_t ldb, void* C, int64_t ldc, int64_t m, int64_t n, int64_t k, double alpha,
+                   double beta, int lower_only);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_H */

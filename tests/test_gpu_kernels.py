@@ -1,0 +1,217 @@
+"""GPU parity tests for the libgpk building blocks (called through the C ABI with torch tensors as
+device memory) against the CPU oracle on the same seeded inputs.  fp64 bars are stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from unmanned_aerial_vehicles_amd.device import get_backend
+    return get_backend(0)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _dp(a):
+    from unmanned_aerial_vehicles_amd import _lib
+    return a.ctypes.data_as(_lib._dp)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_tiles_orientations(be, dtype, ta, tb):
+    """Exact-integer operands (asymmetric) catch swapped fragment / C-D maps in every orientation."""
+    import torch
+    rng = np.random.default_rng(3)
+    m, n, k = 256, 384, 160 if dtype == "f64" else 192
+    A = rng.integers(-4, 5, size=(m, k)).astype(np.float64)
+    B = rng.integers(-4, 5, size=(n, k)).astype(np.float64)
+    Cm = rng.integers(-4, 5, size=(m, n)).astype(np.float64)
+    ref = 2.0 * A @ B.T - 1.0 * Cm
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    Ad = be.upload(A.T.copy() if ta else A, tdt)
+    Bd = be.upload(B.T.copy() if tb else B, tdt)
+    Cd = be.upload(Cm, tdt)
+    from unmanned_aerial_vehicles_amd import _lib
+    be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64 if dtype == "f64" else _lib.GPK_F32, ta, tb, _p(Ad),
+                                   Ad.shape[1], _p(Bd), Bd.shape[1], _p(Cd), n, m, n, k, 2.0, -1.0, 0))
+    out = Cd.double().cpu().numpy()
+    assert np.array_equal(out, ref)
+
+
+def test_gemm_tiles_random_and_lower(be):
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    rng = np.random.default_rng(5)
+    m, k = 512, 1024
+    A = rng.standard_normal((m, k))
+    C0 = rng.standard_normal((m, m))
+    Ad, Cd = be.upload(A), be.upload(C0)
+    be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(Ad), k, _p(Ad), k, _p(Cd), m, m, m, k, -1.0, 1.0, 1))
+    out = Cd.cpu().numpy()
+    ref = C0 - A @ A.T
+    tiles_lower = np.kron(np.tril(np.ones((m // 128, m // 128))), np.ones((128, 128))).astype(bool)
+    assert relerr(out[tiles_lower], ref[tiles_lower]) < 1e-13
+    assert np.array_equal(out[~tiles_lower], C0[~tiles_lower])      # skipped tiles untouched
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,D,ard", [(1000, 9, False), (1000, 10, True), (130, 3, False), (64, 20, True)])
+def test_gram_fp64(be, csv_data, N, D, ard):
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(7)
+    X = csv_data["X10"][:N, :D] if D <= 10 else rng.standard_normal((N, D))
+    ls = 0.3 + 0.1 * np.arange(D) if ard else np.full(D, 0.5)
+    dev = DeviceGP(X, np.zeros((N, 1)), be)
+    dev.gram(ls, 1.7, 0.1001)
+    Kp = dev.K.cpu().numpy()
+    ref = O.rbf_gram(X, ls, 1.7, 0.1001)
+    assert relerr(Kp[:N, :N], ref) < 5e-15 * 20
+    assert np.array_equal(Kp[:N, :N], Kp[:N, :N].T)                 # exactly symmetric
+    pad = Kp.copy()
+    pad[:N, :N] = 0
+    expect = np.zeros_like(pad)
+    idx = np.arange(N, dev.Np)
+    expect[idx, idx] = 1.0
+    assert np.array_equal(pad, expect)                               # identity padding
+
+
+def test_gram_fp32(be, csv_data):
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    X = csv_data["X10"][:777, :9]
+    Np = 896
+    Xd = be.upload(X, torch.float32)
+    K = be.empty((Np, Np), torch.float32)
+    ls = np.full(9, 0.5)
+    be.check(be.lib.gpk_gram(be.h, _lib.GPK_F32, _p(Xd), 777, 9, _dp(ls), 1.0, 0.1, _p(K), Np))
+    ref = O.rbf_gram(X.astype(np.float32).astype(np.float64), 0.5, 1.0, 0.1)
+    assert np.max(np.abs(K.cpu().numpy()[:777, :777] - ref)) < 2e-6
+
+
+def test_cross_gram_t(be, csv_data):
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    X = csv_data["X10"][:300, :9]
+    Xq = csv_data["Xq10"][:50, :9]
+    ls = 0.4 + 0.05 * np.arange(9)
+    for tdt, code, tol in ((torch.float64, _lib.GPK_F64, 1e-13), (torch.float32, _lib.GPK_F32, 2e-6)):
+        B = be.empty((384, 128), tdt)
+        be.check(be.lib.gpk_cross_gram_t(be.h, code, _p(be.upload(X, tdt)), 300, _p(be.upload(Xq, tdt)), 50, 9,
+                                         _dp(ls), 1.3, _p(B), 128))
+        out = B.double().cpu().numpy()
+        ref = O.rbf_cross(Xq, X, ls, 1.3).T
+        assert np.max(np.abs(out[:300, :50] - ref)) < tol * 1.3
+        assert not out[300:].any() and not out[:, 50:].any()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [128, 1000, 1536])
+def test_potrf_potrs_against_oracle(be, csv_data, N):
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(11)
+    if N <= 1000:
+        X, Y = csv_data["X10"][:N, :9], csv_data["Y6"][:N, 3:6]
+    else:
+        X, Y, _ = O.synthetic_problem(N, 1)
+    Yn, _, _ = O.normalize_targets(Y)
+    ls = 0.5 if N <= 1000 else 2.0
+    dev = DeviceGP(X, Yn, be)
+    dev.factorize(ls, 1.0, 0.1001)
+    dev.solve_alpha()
+    st = O.fit_fixed(X, Y, ls, 1.0, 0.1, 1e-4)
+    L = dev.L_host()
+    assert relerr(L, st.L) < 1e-12
+    assert relerr(dev.alpha_host(), st.alpha) < 1e-10
+    # leaf inverses: W_b L_bb = I
+    W = dev.winv.cpu().numpy()
+    Lp = np.tril(dev.K.cpu().numpy())
+    for b in range(dev.Np // 128):
+        blk = Lp[128 * b:128 * b + 128, 128 * b:128 * b + 128]
+        assert np.max(np.abs(W[128 * b:128 * b + 128] @ blk - np.eye(128))) < 1e-11
+    logdet_half, quad = dev.lml_terms()
+    assert abs(logdet_half - np.log(np.diag(st.L)).sum()) < 1e-10 * abs(logdet_half)
+    assert relerr(quad, np.einsum("ik,ik->k", st.Yn, st.alpha)) < 1e-10
+
+
+def test_potrf_not_positive_definite(be):
+    import torch
+    from unmanned_aerial_vehicles_amd._lib import NotPositiveDefinite
+    A = np.eye(256)
+    A[200, 200] = -1.0
+    Ad = be.upload(A)
+    winv = be.empty((256, 128), torch.float64)
+    info = C.c_int(0)
+    with pytest.raises(NotPositiveDefinite):
+        be.check(be.lib.gpk_potrf(be.h, _p(Ad), 256, 256, _p(winv), C.byref(info)))
+    assert info.value == 201
+
+
+def test_trsm_colsumsq_fp64_fp32(be):
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    X, Y, Xq = O.synthetic_problem(700, 200)
+    st = O.fit_fixed(X, Y, 2.0, 1.0, 0.1, 1e-4)
+    dev = DeviceGP(X, st.Yn, be)
+    dev.factorize(2.0, 1.0, 0.1001)
+    from scipy.linalg import solve_triangular
+    Ks = O.rbf_cross(Xq, X, 2.0, 1.0)
+    V = solve_triangular(st.L, Ks.T, lower=True)
+    ref = np.einsum("ij,ij->j", V, V)
+    v64 = dev.predict_var_dev(Xq, 1.1, 0.0, "float64").cpu().numpy()
+    assert relerr(1.1 - v64, ref) < 1e-11
+    v32 = dev.predict_var_dev(Xq, 1.1, 0.0, "float32").cpu().numpy()
+    assert np.max(np.abs(v32 - np.maximum(1.1 - ref, 0))) < 5e-5
+
+
+def test_predict_mean_fp64_fp32(be, csv_data, ka):
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    X, Y = csv_data["X10"], csv_data["Y6"]
+    st = O.fit_fixed(X, Y, 0.5, 1.0, 0.1, 1e-4)
+    dev = DeviceGP(X, st.Yn, be)
+    dev.ls, dev.sf2 = np.full(10, 0.5), 1.0
+    dev.set_alpha(st.alpha)
+    Xq = csv_data["Xq10"]
+    m64 = dev.predict_mean_dev(Xq, st.y_mean, st.y_std, "float64").cpu().numpy()
+    assert relerr(m64, ka["ka1_mean"]) < 1e-11
+    m32 = dev.predict_mean_dev(Xq, st.y_mean, st.y_std, "float32").double().cpu().numpy()
+    assert relerr(m32, ka["ka1_mean"]) < 2e-4
+    # ragged sizes: single query, and M not a multiple of anything
+    for M in (1, 3, 513):
+        q = np.random.default_rng(M).standard_normal((M, 10)) * 0.3 + X[:M]
+        out = dev.predict_mean_dev(q, st.y_mean, st.y_std, "float64").cpu().numpy()
+        assert relerr(out, O.predict(st, q)) < 1e-11
+
+
+def test_lml_gradient_kernels(be, csv_data, ka):
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    X, Y = csv_data["X10"][:, :9], csv_data["Y6"][:, 3:6]
+    st = O.fit_fixed(X, Y, 0.5, 1.0, 0.1, 1e-4)
+    dev = DeviceGP(X, st.Yn, be)
+    dev.factorize(0.5, 1.0, 0.1001)
+    dev.solve_alpha()
+    g = dev.lml_grad(0.1)
+    assert relerr([g[:9].sum(), g[9]], ka["ka2_grad"]) < 1e-9
+    # K^-1 itself (lower tiles)
+    Kinv = dev._Kinv.cpu().numpy()[:1000, :1000]
+    ref = np.linalg.inv(O.rbf_gram(X, 0.5, 1.0, 0.1001))
+    assert relerr(np.tril(Kinv), np.tril(ref)) < 1e-9
+    # ARD, single output
+    y = csv_data["Y6"][:, 3]
+    st = O.fit_fixed(X, y, ka["ka6b_ls"], 1.0, 0.05, 1e-6, normalize_y=False)
+    dev = DeviceGP(X, st.Yn, be)
+    dev.factorize(ka["ka6b_ls"], 1.0, 0.05 + 1e-6)
+    dev.solve_alpha()
+    g = dev.lml_grad(0.05)
+    assert relerr(g[:10], ka["ka6b_grad"]) < 1e-8

@@ -1,0 +1,84 @@
+"""ctypes binding of libgpk.so (include/gpk.h).  No torch types cross this boundary:
+device buffers are passed as integer addresses (`torch.Tensor.data_ptr()`), host arrays as
+`numpy` double pointers.
+
+The library is mandatory: if it is missing or cannot be loaded this module raises — there is
+no CPU fallback for the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._build import LIB_PATH
+
+GPK_F32, GPK_F64 = 0, 1
+GPK_OK, GPK_NOT_PD, GPK_BAD_ARG, GPK_HIP_ERROR = 0, 1, 2, 3
+GPK_TILE, GPK_MAX_D, GPK_MAX_P = 128, 64, 16
+
+_vp, _i64, _int, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/gpk.h one to one
+SIGNATURES = {
+    "gpk_create": (_int, [C.POINTER(_vp), _int]),
+    "gpk_destroy": (None, [_vp]),
+    "gpk_last_error": (C.c_char_p, [_vp]),
+    "gpk_set_stream": (_int, [_vp, _vp]),
+    "gpk_synchronize": (_int, [_vp]),
+    "gpk_padded": (_i64, [_i64]),
+    "gpk_version": (C.c_char_p, []),
+    "gpk_gram": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _i64]),
+    "gpk_cross_gram_t": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _int, _dp, _dbl, _vp, _i64]),
+    "gpk_potrf": (_int, [_vp, _vp, _i64, _i64, _vp, C.POINTER(_int)]),
+    "gpk_leaf_inverses": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "gpk_factor_to_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "gpk_potrs": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp]),
+    "gpk_trsm_lower_left": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _vp, _i64, _i64]),
+    "gpk_colsumsq": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp]),
+    "gpk_predict_mean": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _vp]),
+    "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,
+                               _dbl, _vp, _vp]),
+    "gpk_lml_terms": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int, _dp]),
+    "gpk_potri": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "gpk_lml_grad": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _int, _vp, _i64, _dp]),
+    "gpk_gemm_tiles": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _dbl,
+                              _dbl, _int]),
+}
+
+_lib = None
+
+
+class GPKError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libgpk error {code}: {message}")
+        self.code = code
+
+
+class NotPositiveDefinite(np.linalg.LinAlgError):
+    """Raised where the reference's LAPACK call raises `numpy.linalg.LinAlgError`
+    (scipy.linalg.cholesky at sklearn/gaussian_process/_gpr.py:349)."""
+
+
+def load():
+    """Load libgpk.so and declare every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the GP kernels)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    """Host double array -> POINTER(c_double) (the array must stay alive during the call)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)

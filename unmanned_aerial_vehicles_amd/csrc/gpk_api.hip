@@ -1,0 +1,96 @@
+// Context management and the composite entry points of the libgpk C ABI.
+#include "gpk_internal.h"
+
+extern "C" const char* gpk_version(void) { return "gpk 0.1 (gfx950)"; }
+
+extern "C" int64_t gpk_padded(int64_t n) { return (n + GPK_TILE - 1) / GPK_TILE * GPK_TILE; }
+
+extern "C" int gpk_create(gpk_handle* out, int device) {
+  if (!out) return GPK_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return GPK_HIP_ERROR;
+  if (hipSetDevice(device) != hipSuccess) return GPK_HIP_ERROR;
+  gpk_context* h = new gpk_context();
+  h->device = device;
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&h->d_info, sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->d_small, 4096) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_small, 4096, hipHostMallocDefault) != hipSuccess) {
+    delete h;
+    return GPK_HIP_ERROR;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return GPK_OK;
+}
+
+extern "C" void gpk_destroy(gpk_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->scratch) (void)hipFree(h->scratch);
+  if (h->d_info) (void)hipFree(h->d_info);
+  if (h->d_small) (void)hipFree(h->d_small);
+  if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" const char* gpk_last_error(gpk_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int gpk_set_stream(gpk_handle h, void* stream) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  if (stream) { h->stream = (hipStream_t)stream; h->user_stream = true; }
+  else { h->stream = h->own_stream; h->user_stream = false; }
+  return GPK_OK;
+}
+
+extern "C" int gpk_synchronize(gpk_handle h) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  return GPK_OK;
+}
+
+int gpk_scratch(gpk_handle h, size_t bytes, void** out) {
+  if (bytes > h->scratch_bytes) {
+    // growing: wait for users of the old block, then replace it
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->scratch) GPK_CHECK_HIP(h, hipFree(h->scratch));
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    const size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    GPK_CHECK_HIP(h, hipMalloc(&h->scratch, want));
+    h->scratch_bytes = want;
+  }
+  *out = h->scratch;
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+                               double sf2, const void* L, int64_t Np, int64_t ldl, const void* winv, const void* Xq,
+                               int64_t M, double kss, double floor_, void* work, double* var) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && L && winv && Xq && work && var, "predict_var: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && Np == gpk_padded(N), "predict_var: Np must equal gpk_padded(N)");
+  const int64_t Mp = gpk_padded(M);
+  // B = K*^T (Np x Mp), V = L^-1 B in place, var = kss - colsumsq(V)
+  GPK_TRY(gpk_cross_gram_t(h, dtype, X, N, Xq, M, D, ls, sf2, work, Mp));
+  GPK_TRY(gpk_trsm_lower_left(h, dtype, L, Np, ldl, winv, work, Mp, Mp));
+  // column sums of squares land in var[0..Mp) and are finalised in place
+  GPK_TRY(gpk_colsumsq(h, dtype, work, Np, Mp, Mp, var));
+  return gpk_var_finalize(h, var, M, kss, floor_, var);
+}
+
+extern "C" int gpk_gemm_tiles(gpk_handle h, int dtype, int ta, int tb, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, void* C, int64_t ldc, int64_t m, int64_t n, int64_t k, double alpha,
+                              double beta, int lower_only) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, A && B && C, "gemm_tiles: null pointer");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "gemm_tiles: bad dtype");
+  GPK_REQUIRE(h, m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31), "gemm_tiles: size too large");
+  GemmArgs g = gemm_args(A, lda, ta ? 1 : 0, B, ldb, tb ? 1 : 0, C, ldc, (int)m, (int)n, (int)k, alpha, beta);
+  g.lower_only = lower_only ? 1 : 0;
+  return gpk_gemm(h, dtype, g);
+}

@@ -1,0 +1,341 @@
+// Blocked Cholesky, triangular solves and K^-1 on top of the MFMA tile GEMM.
+//
+// Everything works on matrices padded to whole 128 x 128 tiles (identity in the padding).
+// The factorisation is recursive: potrf(n) = potrf(n/2), trsm, syrk, potrf(n - n/2), so
+// almost all flops land in large fp64-MFMA GEMM launches; the recursion bottoms out in a
+// 128 x 128 leaf factorised inside one workgroup's LDS.  Each leaf's inverse is kept
+// (winv, Np x 128) so that every triangular solve is a chain of GEMMs.
+#include <vector>
+
+#include "gpk_internal.h"
+
+namespace {
+
+constexpr int NB = 128;       // leaf size
+constexpr int LS = NB + 1;    // LDS row stride (doubles)
+
+// ---- leaf: unblocked right-looking Cholesky of one 128 x 128 block in LDS ---------------------
+// Columns stay unscaled during the sweep (u_ij = a_ij - sum_t l_it l_jt); the rank-1 update of
+// step j uses u_ij u_kj / u_jj, and a final pass divides column j by sqrt(u_jj).  One barrier
+// per column.
+__global__ __launch_bounds__(256) void potf2_leaf_kernel(double* __restrict__ A, long long lda, int row0,
+                                                         int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double a[NB * LS];
+  __shared__ double piv[NB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    a[i * LS + j] = (j <= i) ? A[(long long)i * lda + j] : 0.0;
+  }
+  __syncthreads();
+  const int ro = tid >> 1, half = tid & 1;
+  for (int j = 0; j < NB; ++j) {
+    double ajj = a[j * LS + j];
+    if (!(ajj > 0.0)) {                     // not positive definite (or NaN): record, keep going finite
+      if (tid == 0) atomicCAS(info, 0, row0 + j + 1);
+      ajj = 1.0;
+    }
+    if (tid == 0) piv[j] = ajj;
+    const double rinv = 1.0 / ajj;
+    const int i = j + 1 + ro;
+    if (i < NB) {
+      const double s = a[i * LS + j] * rinv;
+      for (int k = j + 1 + half; k <= i; k += 2) a[i * LS + k] = __builtin_fma(-s, a[k * LS + j], a[i * LS + k]);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    if (j <= i) {
+      const double d = __builtin_sqrt(piv[j]);
+      A[(long long)i * lda + j] = (j == i) ? d : a[i * LS + j] / d;
+    }
+  }
+}
+
+// ---- leaf: W = L^-1 of one 128 x 128 lower-triangular block -----------------------------------
+// Column c of W by forward substitution; two threads (different waves) split each dot product,
+// so the (i, k) sweep is wave-uniform and L is read through the scalar path.
+__global__ __launch_bounds__(256) void trtri_leaf_kernel(const double* __restrict__ L, long long ldl,
+                                                         double* __restrict__ W) {
+  __shared__ __attribute__((aligned(16))) double x[NB * LS];   // x[k][c]
+  __shared__ double part[NB];
+  const int tid = threadIdx.x;
+  const int c = tid & 127, half = tid >> 7;
+  for (int i = 0; i < NB; ++i) {
+    const int mid = i >> 1;
+    const int k0 = half ? mid : 0, k1 = half ? i : mid;
+    double s = 0.0;
+    for (int k = k0; k < k1; ++k) s = __builtin_fma(L[(long long)i * ldl + k], x[k * LS + c], s);
+    if (half) part[c] = s;
+    __syncthreads();
+    if (!half) {
+      s += part[c];
+      const double rhs = (i == c) ? 1.0 : 0.0;
+      x[i * LS + c] = (c <= i) ? (rhs - s) / L[(long long)i * ldl + i] : 0.0;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    W[i * NB + j] = x[i * LS + j];
+  }
+}
+
+__global__ void pack_rhs_kernel(const double* __restrict__ Y, long long N, int P, double* __restrict__ Yp,
+                                long long Np) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Np * NB) return;
+  const long long i = e >> 7;
+  const int c = (int)(e & 127);
+  Yp[e] = (i < N && c < P) ? Y[i * P + c] : 0.0;
+}
+__global__ void unpack_rhs_kernel(const double* __restrict__ Yp, long long N, int P, double* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * P) return;
+  const long long i = e / P;
+  const int c = (int)(e - i * P);
+  out[e] = Yp[i * NB + c];
+}
+__global__ void tril_to_f32_kernel(const double* __restrict__ L, long long Np, long long ldl,
+                                   float* __restrict__ Lf, long long ldlf) {
+  // row = blockIdx.x; only the lower triangle and the rest of the diagonal tile are written
+  const long long i = blockIdx.x;
+  const long long j = (long long)blockIdx.y * 256 + threadIdx.x;
+  const long long jend = (i / NB + 1) * NB;
+  if (j >= jend) return;
+  Lf[i * ldlf + j] = (j <= i) ? (float)L[i * ldl + j] : 0.f;
+}
+__global__ void to_f32_kernel(const double* __restrict__ a, long long n, float* __restrict__ b) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) b[e] = (float)a[e];
+}
+__global__ void copy_leaf_kernel(const double* __restrict__ w, double* __restrict__ W, long long ldw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= NB * NB) return;
+  const int i = e >> 7, j = e & 127;
+  W[(long long)i * ldw + j] = w[e];
+}
+// ---- LML terms: sum log diag(L), sum_i y_ip alpha_ip ----------------------------------------------
+__global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict__ L, long long N, long long ldl,
+                                                        const double* __restrict__ Y,
+                                                        const double* __restrict__ alpha, int P,
+                                                        double* __restrict__ out) {
+  // blockIdx.x == 0: log-det term; blockIdx.x == 1 + p: quadratic term of output p
+  __shared__ double red[4];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  double s = 0.0;
+  if (b == 0) {
+    for (long long i = tid; i < N; i += 256) s += log(L[i * ldl + i]);
+  } else {
+    const int p = b - 1;
+    for (long long i = tid; i < N; i += 256) s = __builtin_fma(Y[i * P + p], alpha[i * P + p], s);
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) out[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+inline int half_split(int64_t n) { return (int)(((n / NB) / 2) * NB); }
+
+template <typename T> constexpr int dt();
+template <> constexpr int dt<double>() { return GPK_F64; }
+template <> constexpr int dt<float>() { return GPK_F32; }
+
+// B (m x n) <- B * L^-T, L (n x n) lower; winv = inverse leaves of L (n x 128)
+int trsm_right_rec(gpk_handle h, double* B, int64_t ldb, int64_t m, const double* L, int64_t ldl, int64_t n,
+                   const double* winv) {
+  if (n == NB) {
+    GemmArgs g = gemm_args(B, ldb, 0, winv, NB, 0, B, ldb, (int)m, NB, NB, 1.0, 0.0);
+    return gpk_gemm(h, GPK_F64, g);
+  }
+  const int64_t n1 = half_split(n), n2 = n - n1;
+  GPK_TRY(trsm_right_rec(h, B, ldb, m, L, ldl, n1, winv));
+  // B2 -= B1 * L21^T
+  GemmArgs g = gemm_args(B, ldb, 0, L + n1 * ldl, ldl, 0, B + n1, ldb, (int)m, (int)n2, (int)n1, -1.0, 1.0);
+  GPK_TRY(gpk_gemm(h, GPK_F64, g));
+  return trsm_right_rec(h, B + n1, ldb, m, L + n1 * ldl + n1, ldl, n2, winv + n1 * NB);
+}
+
+int potrf_rec(gpk_handle h, double* A, int64_t lda, int64_t n, double* winv, int64_t row0) {
+  if (n == NB) {
+    hipLaunchKernelGGL(potf2_leaf_kernel, dim3(1), dim3(256), 0, h->stream, A,
+                       (long long)lda, (int)row0, h->d_info);
+    GPK_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(256), 0, h->stream,
+                       (const double*)A, (long long)lda, winv);
+    GPK_LAUNCH_CHECK(h);
+    return GPK_OK;
+  }
+  const int64_t n1 = half_split(n), n2 = n - n1;
+  GPK_TRY(potrf_rec(h, A, lda, n1, winv, row0));
+  double* A21 = A + n1 * lda;
+  double* A22 = A21 + n1;
+  GPK_TRY(trsm_right_rec(h, A21, lda, n2, A, lda, n1, winv));
+  GemmArgs g = gemm_args(A21, lda, 0, A21, lda, 0, A22, lda, (int)n2, (int)n2, (int)n1, -1.0, 1.0);
+  g.lower_only = 1;
+  GPK_TRY(gpk_gemm(h, GPK_F64, g));
+  return potrf_rec(h, A22, lda, n2, winv + n1 * NB, row0 + n1);
+}
+
+// B (n x M) <- L^-1 B
+template <typename T>
+int trsm_left_rec(gpk_handle h, T* B, int64_t ldb, int64_t M, const T* L, int64_t ldl, int64_t n, const T* winv) {
+  if (n == NB) {
+    GemmArgs g = gemm_args(winv, NB, 0, B, ldb, 1, B, ldb, NB, (int)M, NB, 1.0, 0.0);
+    return gpk_gemm(h, dt<T>(), g);
+  }
+  const int64_t n1 = half_split(n), n2 = n - n1;
+  GPK_TRY(trsm_left_rec<T>(h, B, ldb, M, L, ldl, n1, winv));
+  // B2 -= L21 * B1
+  GemmArgs g = gemm_args(L + n1 * ldl, ldl, 0, B, ldb, 1, B + n1 * ldb, ldb, (int)n2, (int)M, (int)n1, -1.0, 1.0);
+  GPK_TRY(gpk_gemm(h, dt<T>(), g));
+  return trsm_left_rec<T>(h, B + n1 * ldb, ldb, M, L + n1 * ldl + n1, ldl, n2, winv + n1 * NB);
+}
+
+// B (n x M) <- L^-T B
+int trsm_left_t_rec(gpk_handle h, double* B, int64_t ldb, int64_t M, const double* L, int64_t ldl, int64_t n,
+                    const double* winv) {
+  if (n == NB) {
+    GemmArgs g = gemm_args(winv, NB, 1, B, ldb, 1, B, ldb, NB, (int)M, NB, 1.0, 0.0);
+    return gpk_gemm(h, GPK_F64, g);
+  }
+  const int64_t n1 = half_split(n), n2 = n - n1;
+  GPK_TRY(trsm_left_t_rec(h, B + n1 * ldb, ldb, M, L + n1 * ldl + n1, ldl, n2, winv + n1 * NB));
+  // B1 -= L21^T * B2   (L21 stored n2 x n1 = k x m)
+  GemmArgs g = gemm_args(L + n1 * ldl, ldl, 1, B + n1 * ldb, ldb, 1, B, ldb, (int)n1, (int)M, (int)n2, -1.0, 1.0);
+  GPK_TRY(gpk_gemm(h, GPK_F64, g));
+  return trsm_left_t_rec(h, B, ldb, M, L, ldl, n1, winv);
+}
+
+// W (n x n, ldw) <- L^-1 (lower); T: scratch at least (n/2) x (n/2) with leading dimension ldt
+int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const double* winv, double* W, int64_t ldw,
+              double* T, int64_t ldt) {
+  if (n == NB) {
+    hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256), dim3(256), 0, h->stream, winv, W, (long long)ldw);
+    GPK_LAUNCH_CHECK(h);
+    return GPK_OK;
+  }
+  const int64_t n1 = half_split(n), n2 = n - n1;
+  GPK_TRY(trtri_rec(h, L, ldl, n1, winv, W, ldw, T, ldt));
+  GPK_TRY(trtri_rec(h, L + n1 * ldl + n1, ldl, n2, winv + n1 * NB, W + n1 * ldw + n1, ldw, T, ldt));
+  // T (n2 x n1) = L21 * W11   (W11 lower: k >= column tile start)
+  GemmArgs g = gemm_args(L + n1 * ldl, ldl, 0, W, ldw, 1, T, ldt, (int)n2, (int)n1, (int)n1, 1.0, 0.0);
+  g.kb_col = NB;
+  GPK_TRY(gpk_gemm(h, GPK_F64, g));
+  // W21 = -W22 * T          (W22 lower: k < row tile end)
+  GemmArgs g2 = gemm_args(W + n1 * ldw + n1, ldw, 0, T, ldt, 1, W + n1 * ldw, ldw, (int)n2, (int)n1, (int)n2, -1.0, 0.0);
+  g2.ke0 = NB; g2.ke_row = NB;
+  return gpk_gemm(h, GPK_F64, g2);
+}
+
+}  // namespace
+
+extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int* info) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, A && winv && info, "potrf: null pointer");
+  GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && lda >= Np && lda % 2 == 0, "potrf: Np must be a positive multiple of 128");
+  GPK_REQUIRE(h, Np < (1ll << 31), "potrf: Np too large");
+  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  GPK_TRY(potrf_rec(h, A, lda, Np, winv, 0));
+  int hinfo = 0;
+  GPK_CHECK_HIP(h, hipMemcpyAsync(&hinfo, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  *info = hinfo;
+  if (hinfo != 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "matrix is not positive definite: leading minor of order %d has a non-positive pivot", hinfo);
+    h->err = buf;
+    return GPK_NOT_PD;
+  }
+  return GPK_OK;
+}
+
+extern "C" int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int64_t ldl, double* winv) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && winv, "leaf_inverses: null pointer");
+  GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && ldl >= Np, "leaf_inverses: Np must be a positive multiple of 128");
+  for (int64_t b = 0; b < Np / NB; ++b) {
+    hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(256), 0, h->stream, L + b * NB * ldl + b * NB,
+                       (long long)ldl, winv + b * NB * NB);
+    GPK_LAUNCH_CHECK(h);
+  }
+  return GPK_OK;
+}
+
+extern "C" int gpk_factor_to_f32(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+                                 float* Lf, int64_t ldlf, float* winvf) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && winv && Lf && winvf, "factor_to_f32: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldl >= Np && ldlf >= Np, "factor_to_f32: bad size");
+  hipLaunchKernelGGL(tril_to_f32_kernel, dim3((unsigned)Np, (unsigned)((Np + 255) / 256)), dim3(256), 0, h->stream, L,
+                     (long long)Np, (long long)ldl, Lf, (long long)ldlf);
+  GPK_LAUNCH_CHECK(h);
+  const long long n = Np * NB;
+  hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, winv, n, winvf);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_potrs(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+                         const double* Y, int64_t N, int P, double* alpha) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && winv && Y && alpha, "potrs: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && N >= 1 && N <= Np && ldl >= Np, "potrs: bad sizes");
+  GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P, "potrs: P must be in [1, 16]");
+  void* ws = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)Np * NB * sizeof(double), &ws));
+  double* Yp = (double*)ws;
+  const long long tot = Np * NB;
+  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, Y,
+                     (long long)N, P, Yp, (long long)Np);
+  GPK_LAUNCH_CHECK(h);
+  GPK_TRY(trsm_left_rec<double>(h, Yp, NB, NB, L, ldl, Np, winv));
+  GPK_TRY(trsm_left_t_rec(h, Yp, NB, NB, L, ldl, Np, winv));
+  hipLaunchKernelGGL(unpack_rhs_kernel, dim3((unsigned)((N * P + 255) / 256)), dim3(256), 0, h->stream,
+                     (const double*)Yp, (long long)N, P, alpha);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_trsm_lower_left(gpk_handle h, int dtype, const void* L, int64_t Np, int64_t ldl,
+                                   const void* winv, void* B, int64_t Mp, int64_t ldb) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && winv && B, "trsm: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && Mp % NB == 0 && Np > 0 && Mp > 0 && ldl >= Np && ldb >= Mp, "trsm: sizes must be multiples of 128");
+  if (dtype == GPK_F64)
+    return trsm_left_rec<double>(h, (double*)B, ldb, Mp, (const double*)L, ldl, Np, (const double*)winv);
+  GPK_REQUIRE(h, dtype == GPK_F32, "trsm: bad dtype");
+  return trsm_left_rec<float>(h, (float*)B, ldb, Mp, (const float*)L, ldl, Np, (const float*)winv);
+}
+
+extern "C" int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y,
+                             const double* alpha, int P, double* terms) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && Y && alpha && terms, "lml_terms: null pointer");
+  GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P && N >= 1, "lml_terms: bad sizes");
+  hipLaunchKernelGGL(lml_terms_kernel, dim3(1 + P), dim3(256), 0, h->stream, L, (long long)N, (long long)ldl, Y,
+                     alpha, P, h->d_small);
+  GPK_LAUNCH_CHECK(h);
+  GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, (1 + P) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 1 + P; ++i) terms[i] = h->h_small[i];
+  return GPK_OK;
+}
+
+extern "C" int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* Kinv,
+                         int64_t ldk, double* work) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && winv && Kinv && work, "potri: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldl >= Np && ldk >= Np, "potri: Np must be a multiple of 128");
+  // work holds W = L^-1 (Np x Np; only lower and diagonal tiles are written or read);
+  // Kinv doubles as the recursion scratch T before it is written
+  double* W = work;
+  GPK_TRY(trtri_rec(h, L, ldl, Np, winv, W, Np, Kinv, ldk));
+  // Kinv (lower tiles) = W^T W: C[i][j] = sum_{k >= i} W[k][i] W[k][j]
+  GemmArgs g = gemm_args(W, Np, 1, W, Np, 1, Kinv, ldk, (int)Np, (int)Np, (int)Np, 1.0, 0.0);
+  g.lower_only = 1;
+  g.kb_row = NB;
+  return gpk_gemm(h, GPK_F64, g);
+}

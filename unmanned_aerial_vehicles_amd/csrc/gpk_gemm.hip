@@ -1,0 +1,321 @@
+// Dense tile GEMM on the gfx950 matrix cores: the workhorse behind the blocked Cholesky
+// (syrk / trsm / gemm updates), the triangular solves and K^-1.
+//
+//   C[m x n] = alpha * opA(A) * opB(B)^T + beta * C        (whole 128 x 128 tiles)
+//
+// fp64 uses v_mfma_f64_16x16x4_f64, fp32 uses v_mfma_f32_32x32x2_f32 (exact f32).  One
+// workgroup = 4 waves (2 x 2), each wave owns a 64 x 64 sub-tile; the k-loop stages
+// 128 rows x 128 bytes of each operand through LDS with register prefetch of the next
+// k-tile (one barrier per k-tile, two LDS buffers).  Operands may be stored k-contiguous
+// or k-strided; the LDS image keeps the global orientation and only the fragment reads
+// differ.  blockIdx is remapped so that each XCD (private L2) sweeps a compact group of
+// tiles that share operand panels.
+#include "gpk_internal.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int LDS_N_STRIDE = 144;    // bytes per row of a k-contiguous tile (128 + 16 pad)
+constexpr int LDS_OP_BYTES = 128 * LDS_N_STRIDE;  // 18432, also >= k-strided image
+
+template <typename T> struct Cfg;
+template <> struct Cfg<double> {
+  static constexpr int BK = 16;           // k elements per tile
+  static constexpr int T_STRIDE = 132;    // elements per row of a k-strided tile
+};
+template <> struct Cfg<float> {
+  static constexpr int BK = 32;
+  static constexpr int T_STRIDE = 132;
+};
+
+struct KParams {
+  const char* A;
+  const char* B;
+  char* C;
+  long long lda, ldb, ldc;  // in elements
+  int m, n, k;
+  double alpha, beta;
+  int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col, heavy_first;
+  int ntm, ntn;
+};
+
+struct V16 { unsigned int x, y, z, w; };
+
+// ---- global -> registers: 4 x 16 B per thread per operand -------------------------------
+template <typename T, bool TR>
+__device__ __forceinline__ void load_tile(const T* __restrict__ base, long long ld, int row0, int k0,
+                                          int tid, V16 (&r)[4]) {
+  constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+  if constexpr (!TR) {
+    // stored (rows x k): thread -> chunk c of row (tid>>3) + 32p
+    const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const T* g = base + (long long)(row0 + rr + 32 * p) * ld + k0 + c * EPC;
+      r[p] = *reinterpret_cast<const V16*>(g);
+    }
+  } else {
+    // stored (k x rows): BK k-rows of 128 elements
+    constexpr int CPR = 128 / EPC;       // chunks per k-row: 64 (f64) / 32 (f32)
+    constexpr int RPP = 256 / CPR;       // k-rows per pass: 4 / 8
+    const int c = tid % CPR, kr = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const T* g = base + (long long)(k0 + kr + RPP * p) * ld + row0 + c * EPC;
+      r[p] = *reinterpret_cast<const V16*>(g);
+    }
+  }
+}
+
+template <typename T, bool TR>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[4]) {
+  constexpr int EPC = 16 / sizeof(T);
+  if constexpr (!TR) {
+    const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      *reinterpret_cast<V16*>(lds + (rr + 32 * p) * LDS_N_STRIDE + c * 16) = r[p];
+  } else {
+    constexpr int CPR = 128 / EPC;
+    constexpr int RPP = 256 / CPR;
+    constexpr int RS = Cfg<T>::T_STRIDE * sizeof(T);
+    const int c = tid % CPR, kr = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      *reinterpret_cast<V16*>(lds + (kr + RPP * p) * RS + c * 16) = r[p];
+  }
+}
+
+// ---- fp64: 4 x 4 blocks of 16x16x4 per wave ------------------------------------------------
+template <bool TA, bool TB>
+__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane,
+                                             d4 (&acc)[4][4]) {
+  const int r = lane & 15, kq = lane >> 4;
+  constexpr int RS = Cfg<double>::T_STRIDE * 8;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    double af[4][2], bf[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if constexpr (!TA) {
+        const double2 v = *reinterpret_cast<const double2*>(la + (wm * 64 + 16 * a + r) * LDS_N_STRIDE +
+                                                            (4 * kq + 2 * hh) * 8);
+        af[a][0] = v.x; af[a][1] = v.y;
+      } else {
+        af[a][0] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh) * RS + (wm * 64 + 16 * a + r) * 8);
+        af[a][1] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh + 1) * RS + (wm * 64 + 16 * a + r) * 8);
+      }
+      if constexpr (!TB) {
+        const double2 v = *reinterpret_cast<const double2*>(lb + (wn * 64 + 16 * a + r) * LDS_N_STRIDE +
+                                                            (4 * kq + 2 * hh) * 8);
+        bf[a][0] = v.x; bf[a][1] = v.y;
+      } else {
+        bf[a][0] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh) * RS + (wn * 64 + 16 * a + r) * 8);
+        bf[a][1] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh + 1) * RS + (wn * 64 + 16 * a + r) * 8);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+  }
+}
+
+// ---- fp32: 2 x 2 blocks of 32x32x2 per wave -------------------------------------------------
+template <bool TA, bool TB>
+__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane,
+                                             f16v (&acc)[2][2]) {
+  const int r = lane & 31, kq = lane >> 5;
+  constexpr int RS = Cfg<float>::T_STRIDE * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // 4 groups of 4 k-steps
+    float af[2][4], bf[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      if constexpr (!TA) {
+        const float4 v = *reinterpret_cast<const float4*>(la + (wm * 64 + 32 * a + r) * LDS_N_STRIDE +
+                                                          (16 * kq + 4 * q) * 4);
+        af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          af[a][t] = *reinterpret_cast<const float*>(la + (16 * kq + 4 * q + t) * RS + (wm * 64 + 32 * a + r) * 4);
+      }
+      if constexpr (!TB) {
+        const float4 v = *reinterpret_cast<const float4*>(lb + (wn * 64 + 32 * a + r) * LDS_N_STRIDE +
+                                                          (16 * kq + 4 * q) * 4);
+        bf[a][0] = v.x; bf[a][1] = v.y; bf[a][2] = v.z; bf[a][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          bf[a][t] = *reinterpret_cast<const float*>(lb + (16 * kq + 4 * q + t) * RS + (wn * 64 + 32 * a + r) * 4);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void zero_acc(d4 (&acc)[4][4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+}
+__device__ __forceinline__ void zero_acc(f16v (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+}
+
+// C/D maps: f64 16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg;
+//           f32 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void store_acc(double* __restrict__ C, long long ldc, int row0, int col0,
+                                          int wm, int wn, int lane, const d4 (&acc)[4][4], double alpha,
+                                          double beta) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wm * 64 + 16 * a + (lane >> 4) + 4 * i;
+        const int col = col0 + wn * 64 + 16 * b + (lane & 15);
+        double* p = C + (long long)row * ldc + col;
+        double v = alpha * acc[a][b][i];
+        if (beta != 0.0) v += beta * (*p);
+        *p = v;
+      }
+}
+__device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, int row0, int col0,
+                                          int wm, int wn, int lane, const f16v (&acc)[2][2], double alpha,
+                                          double beta) {
+  const float al = (float)alpha, be = (float)beta;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = row0 + wm * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int col = col0 + wn * 64 + 32 * b + (lane & 31);
+        float* p = C + (long long)row * ldc + col;
+        float v = al * acc[a][b][i];
+        if (be != 0.f) v += be * (*p);
+        *p = v;
+      }
+}
+
+template <typename T> struct AccT;
+template <> struct AccT<double> { typedef d4 type[4][4]; };
+template <> struct AccT<float> { typedef f16v type[2][2]; };
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * LDS_OP_BYTES];
+  constexpr int BK = Cfg<T>::BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile mapping: each XCD sweeps a contiguous range of a grouped order ----
+  const int nb = gridDim.x, pid = blockIdx.x;
+  const int xcd = pid & 7, q = nb >> 3, rem = nb & 7;
+  const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (pid >> 3);
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * p.ntn;
+  const int group = id / in_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.ntm - first_m, GROUP_M);
+  int tm = first_m + (id % in_group) % gsize;
+  const int tn = (id % in_group) / gsize;
+  if (p.heavy_first) tm = p.ntm - 1 - tm;
+  if (p.lower_only && tn > tm) return;
+
+  int kb = p.kb0 + p.kb_row * tm + p.kb_col * tn;
+  int ke = p.ke0 < 0 ? p.k : p.ke0 + p.ke_row * tm + p.ke_col * tn;
+  kb = max(kb, 0);
+  ke = min(ke, p.k);
+  const int nkt = (ke - kb) / BK;
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+  T* C = reinterpret_cast<T*>(p.C);
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  typename AccT<T>::type acc;
+  zero_acc(acc);
+
+  if (nkt > 0) {
+    V16 ra[4], rb[4];
+    load_tile<T, TA>(A, p.lda, row0, kb, tid, ra);
+    load_tile<T, TB>(B, p.ldb, col0, kb, tid, rb);
+    store_tile<T, TA>(lds, tid, ra);
+    store_tile<T, TB>(lds + LDS_OP_BYTES, tid, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < nkt;
+      if (more) {
+        load_tile<T, TA>(A, p.lda, row0, kb + (kt + 1) * BK, tid, ra);
+        load_tile<T, TB>(B, p.ldb, col0, kb + (kt + 1) * BK, tid, rb);
+      }
+      compute_tile<TA, TB>(lds + cur * 2 * LDS_OP_BYTES, lds + cur * 2 * LDS_OP_BYTES + LDS_OP_BYTES, wm, wn,
+                           lane, acc);
+      if (more) {
+        store_tile<T, TA>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
+        store_tile<T, TB>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
+      }
+      __syncthreads();
+    }
+  }
+  store_acc(C, p.ldc, row0, col0, wm, wn, lane, acc, p.alpha, p.beta);
+}
+
+template <typename T>
+int launch(gpk_handle h, const GemmArgs& g) {
+  KParams p;
+  p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
+  p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
+  p.m = g.m; p.n = g.n; p.k = g.k;
+  p.alpha = g.alpha; p.beta = g.beta;
+  p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
+  p.ke0 = g.ke0; p.ke_row = g.ke_row; p.ke_col = g.ke_col;
+  p.heavy_first = g.heavy_first;
+  p.ntm = g.m / BM; p.ntn = g.n / BN;
+  dim3 grid(p.ntm * p.ntn), block(256);
+  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, h->stream, p);
+  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, h->stream, p);
+  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, h->stream, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, h->stream, p);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+}  // namespace
+
+int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
+  const int bk = dtype == GPK_F64 ? 16 : 32;
+  GPK_REQUIRE(h, g.m > 0 && g.n > 0 && g.m % BM == 0 && g.n % BN == 0, "gemm: m, n must be multiples of 128");
+  GPK_REQUIRE(h, g.k >= 0 && g.k % bk == 0, "gemm: k must be a multiple of the k-tile");
+  GPK_REQUIRE(h, g.kb0 % bk == 0 && g.kb_row % bk == 0 && g.kb_col % bk == 0 && (g.ke0 < 0 || g.ke0 % bk == 0) &&
+                     g.ke_row % bk == 0 && g.ke_col % bk == 0,
+              "gemm: k-range coefficients must be multiples of the k-tile");
+  const int es = dtype == GPK_F64 ? 8 : 4;
+  GPK_REQUIRE(h, (g.lda * es) % 16 == 0 && (g.ldb * es) % 16 == 0, "gemm: leading dimensions must be 16-byte multiples");
+  GPK_REQUIRE(h, ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: operands must be 16-byte aligned");
+  return dtype == GPK_F64 ? launch<double>(h, g) : launch<float>(h, g);
+}

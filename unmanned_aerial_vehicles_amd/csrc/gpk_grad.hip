@@ -1,0 +1,213 @@
+// K6b: fused log-marginal-likelihood gradient reduction.
+//
+//   g_d     = 1/2 sum_ij Q_ij K_ij ((x_id - x_jd) / ls_d)^2          d = 0 .. D-1
+//   g_noise = 1/2 noise sum_i Q_ii
+//   g_sf2   = 1/2 sum_ij Q_ij K_ij                                   (K_ij = sf2 exp(-d2_ij / 2))
+//   Q_ij    = sum_p alpha_ip alpha_jp - P Kinv_ij
+//
+// One streaming pass over the lower triangle of K^-1 (HBM-bound: N^2/2 doubles); K_ij and the
+// per-feature factors are recomputed from X on the fly, so neither K nor the N x N x D
+// gradient tensor of the reference is ever materialised.  64 x 64 tiles, 4 x 4 per thread;
+// strictly-lower elements count twice (symmetry).  Block partials are reduced in a fixed
+// order by a second kernel (deterministic).
+#include "gpk_internal.h"
+
+namespace {
+
+constexpr int TS = 64, DMAXG = 16, GW = DMAXG + 2;   // block partial: D (<= 16) + noise + sf2
+struct LsG { double v[DMAXG]; };
+
+__device__ __forceinline__ double exp_neg64(double x) {
+  x = fmax(x, -800.0);
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(k, -6.93147180559945286227e-01, x);
+  r = __builtin_fma(k, -2.31904681384629955842e-17, r);
+  double p = 1.6059043836821613e-10;
+  p = __builtin_fma(p, r, 2.08767569878680990e-09);
+  p = __builtin_fma(p, r, 2.50521083854417188e-08);
+  p = __builtin_fma(p, r, 2.75573192239858907e-07);
+  p = __builtin_fma(p, r, 2.75573192239858907e-06);
+  p = __builtin_fma(p, r, 2.48015873015873016e-05);
+  p = __builtin_fma(p, r, 1.98412698412698413e-04);
+  p = __builtin_fma(p, r, 1.38888888888888889e-03);
+  p = __builtin_fma(p, r, 8.33333333333333333e-03);
+  p = __builtin_fma(p, r, 4.16666666666666667e-02);
+  p = __builtin_fma(p, r, 1.66666666666666667e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)k);
+}
+
+// grid-stride over lower-triangular 64 x 64 tiles; D <= 16
+__global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict__ X, long long N, int D, LsG ls,
+                                                       double sf2, const double* __restrict__ alpha, int P,
+                                                       const double* __restrict__ Kinv, long long ldk,
+                                                       long long ntiles, double* __restrict__ partial) {
+  __shared__ double xi[DMAXG * TS], xj[DMAXG * TS];
+  __shared__ double ai[GPK_MAX_P * TS], aj[GPK_MAX_P * TS];
+  __shared__ double red[4][GW];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  double g_noise = 0.0, g_sf2 = 0.0;
+  double gd[DMAXG];
+#pragma unroll
+  for (int d = 0; d < DMAXG; ++d) gd[d] = 0.0;
+
+  for (long long id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    long long ti = (long long)((__builtin_sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+    while (ti * (ti + 1) / 2 > id) --ti;
+    const long long tj = id - ti * (ti + 1) / 2;
+    const long long i0 = ti * TS, j0 = tj * TS;
+    __syncthreads();
+    for (int e = tid; e < TS * D; e += 256) {
+      const int i = e / D, d = e - i * D;
+      xi[d * TS + i] = (i0 + i < N) ? X[(i0 + i) * D + d] / ls.v[d] : 0.0;
+      xj[d * TS + i] = (j0 + i < N) ? X[(j0 + i) * D + d] / ls.v[d] : 0.0;
+    }
+    for (int e = tid; e < TS * P; e += 256) {
+      const int i = e / P, p = e - i * P;
+      ai[p * TS + i] = (i0 + i < N) ? alpha[(i0 + i) * P + p] : 0.0;
+      aj[p * TS + i] = (j0 + i < N) ? alpha[(j0 + i) * P + p] : 0.0;
+    }
+    __syncthreads();
+
+    // pass 1: squared distances and alpha_i . alpha_j
+    double d2[4][4], q[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { d2[r][c] = 0.0; q[r][c] = 0.0; }
+    for (int d = 0; d < D; ++d) {
+      double a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = xi[d * TS + 4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = xj[d * TS + 4 * tx + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const double df = a[r] - b[c]; d2[r][c] = __builtin_fma(df, df, d2[r][c]); }
+    }
+    for (int p = 0; p < P; ++p) {
+      double a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = ai[p * TS + 4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = aj[p * TS + 4 * tx + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[r][c] = __builtin_fma(a[r], b[c], q[r][c]);
+    }
+    // coefficient w_ij Q_ij K_ij  (w = 2 strictly below the diagonal, 1 on it, 0 above / padding)
+    double coef[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long gi = i0 + 4 * ty + r;
+      const double2 k01 = *reinterpret_cast<const double2*>(Kinv + gi * ldk + j0 + 4 * tx);
+      const double2 k23 = *reinterpret_cast<const double2*>(Kinv + gi * ldk + j0 + 4 * tx + 2);
+      const double kin[4] = {k01.x, k01.y, k23.x, k23.y};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long long gj = j0 + 4 * tx + c;
+        const bool live = gi < N && gj < N && gj <= gi;
+        const double w = live ? (gj == gi ? 1.0 : 2.0) : 0.0;
+        const double Q = q[r][c] - (double)P * (live ? kin[c] : 0.0);
+        const double kv = sf2 * exp_neg64(-0.5 * d2[r][c]);
+        coef[r][c] = w * Q * kv;
+        g_sf2 += coef[r][c];
+        if (live && gj == gi) g_noise += Q;
+      }
+    }
+    // pass 2: per-feature factors
+#pragma unroll
+    for (int d = 0; d < DMAXG; ++d) {
+      if (d < D) {
+        double a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = xi[d * TS + 4 * ty + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = xj[d * TS + 4 * tx + c];
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const double df = a[r] - b[c]; s = __builtin_fma(coef[r][c], df * df, s); }
+        gd[d] += s;
+      }
+    }
+  }
+
+  // block reduction: wave shuffle, then 4 waves through LDS
+  const int lane = tid & 63, wave = tid >> 6;
+  auto wave_sum = [](double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+  };
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < DMAXG; ++d) {
+    const double v = wave_sum(gd[d]);
+    if (lane == 0) red[wave][d] = v;
+  }
+  {
+    const double vn = wave_sum(g_noise), vs = wave_sum(g_sf2);
+    if (lane == 0) { red[wave][DMAXG] = vn; red[wave][DMAXG + 1] = vs; }
+  }
+  __syncthreads();
+  if (tid < GW) partial[(long long)blockIdx.x * GW + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ partial, int nblocks,
+                                                          double* __restrict__ out) {
+  // one workgroup per output component; fixed-order strided sum + tree
+  __shared__ double red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0;
+  for (int b = tid; b < nblocks; b += 256) s += partial[(long long)b * GW + c];
+  red[tid] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) out[c] = red[0];
+}
+
+}  // namespace
+
+extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2,
+                            double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
+                            double* grad) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && ls && alpha && Kinv && grad, "lml_grad: null pointer");
+  GPK_REQUIRE(h, N >= 1 && D >= 1 && D <= DMAXG && P >= 1 && P <= GPK_MAX_P, "lml_grad: D must be in [1, 16], P in [1, 16]");
+  const int64_t Np = gpk_padded(N);
+  GPK_REQUIRE(h, ldk >= Np && ldk % 2 == 0 && ((uintptr_t)Kinv % 16) == 0, "lml_grad: Kinv must be padded and 16-byte aligned");
+  LsG l;
+  for (int d = 0; d < DMAXG; ++d) l.v[d] = 1.0;
+  for (int d = 0; d < D; ++d) {
+    GPK_REQUIRE(h, ls[d] > 0.0, "lml_grad: length-scales must be positive");
+    l.v[d] = ls[d];
+  }
+  const int64_t nt = Np / TS, ntiles = nt * (nt + 1) / 2;
+  const int nblocks = (int)(ntiles < 4096 ? ntiles : 4096);
+  void* ws = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)(nblocks + 1) * GW * sizeof(double), &ws));
+  double* partial = (double*)ws;
+  double* out = partial + (size_t)nblocks * GW;
+  hipLaunchKernelGGL(lml_grad_kernel, dim3(nblocks), dim3(256), 0, h->stream, X, (long long)N, D, l, sf2, alpha, P,
+                     Kinv, (long long)ldk, (long long)ntiles, partial);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(GW), dim3(256), 0, h->stream, (const double*)partial,
+                     nblocks, out);
+  GPK_LAUNCH_CHECK(h);
+  double host[GW];
+  GPK_CHECK_HIP(h, hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  for (int d = 0; d < D; ++d) grad[d] = 0.5 * host[d];
+  grad[D] = 0.5 * noise * host[DMAXG];
+  grad[D + 1] = 0.5 * host[DMAXG + 1];
+  return GPK_OK;
+}

@@ -1,0 +1,480 @@
+// RBF kernel-matrix kernels for gfx950:
+//   K1  gram_sym_kernel    symmetric N x N Gram build (HBM write-bound; computes each
+//                          64 x 64 tile once and writes it to both triangles)
+//       cross_t_kernel     K*^T block (training index major) feeding the variance solve
+//   K4  predict_mean_kernel fused k(xq, X) . alpha, K* never stored
+//       colsumsq kernels   column sums of squares of V = L^-1 K*^T (fp64 accumulation)
+// Squared distances are formed from exact differences of inputs pre-divided by the
+// length-scale (the cdist/pdist form of the reference), never by the norm expansion.
+#include "gpk_internal.h"
+
+namespace {
+
+struct LsArr { double v[GPK_MAX_D]; };
+struct PArr { double v[GPK_MAX_P]; };
+struct Ls16 { double v[16]; };
+
+// ---- exp(x) for x <= 0 ---------------------------------------------------------------------
+// fp64: k = rint(x log2e), r = x - k ln2 (hi/lo split, FMA), Taylor degree 13 on |r| <= ln2/2
+// (truncation 4e-18 relative), scaled by 2^k with v_ldexp_f64 (gradual underflow to 0).
+__device__ __forceinline__ double exp_neg(double x) {
+  x = fmax(x, -800.0);
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(k, -6.93147180559945286227e-01, x);
+  r = __builtin_fma(k, -2.31904681384629955842e-17, r);
+  double p = 1.6059043836821613e-10;                   // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878680990e-09);    // 1/12!
+  p = __builtin_fma(p, r, 2.50521083854417188e-08);    // 1/11!
+  p = __builtin_fma(p, r, 2.75573192239858907e-07);    // 1/10!
+  p = __builtin_fma(p, r, 2.75573192239858907e-06);    // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873016e-05);    // 1/8!
+  p = __builtin_fma(p, r, 1.98412698412698413e-04);    // 1/7!
+  p = __builtin_fma(p, r, 1.38888888888888889e-03);    // 1/6!
+  p = __builtin_fma(p, r, 8.33333333333333333e-03);    // 1/5!
+  p = __builtin_fma(p, r, 4.16666666666666667e-02);    // 1/4!
+  p = __builtin_fma(p, r, 1.66666666666666667e-01);    // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)k);
+}
+// fp32: v_exp_f32 on x*log2e with the product's rounding error folded back in.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+  const float hi = x * L2E_HI;
+  const float lo = __builtin_fmaf(x, L2E_HI, -hi) + x * L2E_LO;
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return __builtin_fmaf(e, lo * 0.693147180559945f, e);
+}
+
+template <typename T> struct Vec16;
+template <> struct Vec16<double> { typedef double2 type; static constexpr int N = 2; };
+template <> struct Vec16<float> { typedef float4 type; static constexpr int N = 4; };
+
+__device__ __forceinline__ void st16(double* p, double a, double b, bool nt) {
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  dv2 v = {a, b};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<dv2*>(p));
+  else *reinterpret_cast<dv2*>(p) = v;
+}
+__device__ __forceinline__ void st16(float* p, float a, float b, float c, float d, bool nt) {
+  typedef float fv4 __attribute__((ext_vector_type(4)));
+  fv4 v = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<fv4*>(p));
+  else *reinterpret_cast<fv4*>(p) = v;
+}
+__device__ __forceinline__ void store_row4(double* p, const double (&v)[4], bool nt) {
+  st16(p, v[0], v[1], nt);
+  st16(p + 2, v[2], v[3], nt);
+}
+__device__ __forceinline__ void store_row4(float* p, const float (&v)[4], bool nt) {
+  st16(p, v[0], v[1], v[2], v[3], nt);
+}
+
+constexpr int TS = 64;    // tile edge
+constexpr int DCH = 16;   // feature chunk held in LDS
+
+// Stage rows [r0, r0+64) of X (n x D) scaled by 1/ls into lds[d][64] for d in [d0, d0+dc).
+template <typename T>
+__device__ __forceinline__ void stage_x(const T* __restrict__ X, long long n, int D, long long r0, int d0,
+                                        int dc, const LsArr& ls, T* lds, int tid) {
+  for (int e = tid; e < TS * dc; e += 256) {
+    const int i = e / dc, d = e - i * dc;
+    const long long gi = r0 + i;
+    T v = T(0);
+    if (gi < n) v = X[gi * D + d0 + d] / T(ls.v[d0 + d]);
+    lds[d * TS + i] = v;
+  }
+}
+
+// 4 x 4 micro-tile of squared distances accumulated over one feature chunk.
+template <typename T>
+__device__ __forceinline__ void accum_d2(const T* xi, const T* xj, int dc, int ty, int tx, T (&d2)[4][4]) {
+  for (int d = 0; d < dc; ++d) {
+    T a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = xi[d * TS + 4 * ty + r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = xj[d * TS + 4 * tx + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T df = a[r] - b[c];
+        d2[r][c] = __builtin_fma(df, df, d2[r][c]);
+      }
+  }
+}
+
+// ---- K1: symmetric Gram build ---------------------------------------------------------------
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ X, long long N, int D, LsArr ls,
+                                                       T sf2, T diag_add, T* __restrict__ K, long long ldk) {
+  __shared__ __attribute__((aligned(16))) T xi[DCH * TS];
+  __shared__ __attribute__((aligned(16))) T xj[DCH * TS];
+  __shared__ __attribute__((aligned(16))) T tb[TS * (TS + 1)];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+
+  // linear id -> lower-triangular tile (ti >= tj)
+  const long long id = blockIdx.x;
+  long long ti = (long long)((__builtin_sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+  while (ti * (ti + 1) / 2 > id) --ti;
+  const long long tj = id - ti * (ti + 1) / 2;
+  const long long i0 = ti * TS, j0 = tj * TS;
+
+  T d2[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d2[r][c] = T(0);
+
+  for (int dbase = 0; dbase < D; dbase += DCH) {
+    const int dc = min(DCH, D - dbase);
+    if (dbase) __syncthreads();
+    stage_x<T>(X, N, D, i0, dbase, dc, ls, xi, tid);
+    stage_x<T>(X, N, D, j0, dbase, dc, ls, xj, tid);
+    __syncthreads();
+    accum_d2<T>(xi, xj, dc, ty, tx, d2);
+  }
+
+  T v[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long gi = i0 + 4 * ty + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long long gj = j0 + 4 * tx + c;
+      T val = sf2 * exp_neg(T(-0.5) * d2[r][c]);
+      if (gi == gj) val = sf2 + diag_add;            // RBF diagonal is exactly sf2 (+ white + jitter)
+      if (gi >= N || gj >= N) val = (gi == gj) ? T(1) : T(0);   // identity padding
+      v[r][c] = val;
+    }
+    store_row4(K + gi * ldk + j0 + 4 * tx, v[r], NT);
+  }
+  if (ti == tj) return;
+
+  // mirrored tile: transpose through LDS, write rows of K[j-block][i-block]
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tb[(4 * ty + r) * (TS + 1) + 4 * tx + c] = v[r][c];
+  __syncthreads();
+  constexpr int VEC = Vec16<T>::N;      // elements per 16-byte store
+  constexpr int LPR = TS / VEC;         // lanes per output row
+  constexpr int RPG = TS / (256 / LPR); // rows per lane group
+  const int lp = tid % LPR, g = tid / LPR;
+#pragma unroll
+  for (int rr = 0; rr < RPG; ++rr) {
+    const int jj = g * RPG + rr;
+    T w[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) w[e] = tb[(VEC * lp + e) * (TS + 1) + jj];
+    T* dst = K + (j0 + jj) * ldk + i0 + VEC * lp;
+    if constexpr (VEC == 2) st16(dst, w[0], w[1], NT);
+    else st16(dst, w[0], w[1], w[2], w[3], NT);
+  }
+}
+
+// ---- K*^T block: B[j][m] = sf2 exp(-0.5 |x_j - xq_m|^2), zero in the padding -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, long long N,
+                                                      const T* __restrict__ Xq, long long M, int D, LsArr ls,
+                                                      T sf2, T* __restrict__ B, long long ldb) {
+  __shared__ __attribute__((aligned(16))) T xi[DCH * TS];
+  __shared__ __attribute__((aligned(16))) T xj[DCH * TS];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const long long i0 = (long long)blockIdx.y * TS, j0 = (long long)blockIdx.x * TS;  // i: train, j: query
+  T d2[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d2[r][c] = T(0);
+  for (int dbase = 0; dbase < D; dbase += DCH) {
+    const int dc = min(DCH, D - dbase);
+    if (dbase) __syncthreads();
+    stage_x<T>(X, N, D, i0, dbase, dc, ls, xi, tid);
+    stage_x<T>(Xq, M, D, j0, dbase, dc, ls, xj, tid);
+    __syncthreads();
+    accum_d2<T>(xi, xj, dc, ty, tx, d2);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long gi = i0 + 4 * ty + r;
+    T v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long long gj = j0 + 4 * tx + c;
+      T val = sf2 * exp_neg(T(-0.5) * d2[r][c]);
+      if (gi >= N || gj >= M) val = T(0);
+      v[c] = val;
+    }
+    store_row4(B + gi * ldb + j0 + 4 * tx, v, false);
+  }
+}
+
+// ---- K4: fused posterior mean ---------------------------------------------------------------------
+// One thread owns QPT queries (coordinates and P accumulators in registers); training rows
+// [x_j / ls | alpha_j] are staged through LDS and read as wave-uniform broadcasts.  The training
+// set is split over gridDim.y; partial sums are combined in a fixed order by mean_reduce_kernel.
+constexpr int PM_DMAX = 16, PM_PMAX = 16, PM_TJ = 128, PM_QPT = 2;
+
+template <typename T>
+__global__ __launch_bounds__(256) void predict_mean_kernel(const T* __restrict__ X, const T* __restrict__ alpha,
+                                                           long long N, int D, int P, Ls16 ls,
+                                                           const T* __restrict__ Xq, long long M,
+                                                           long long chunk, T* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) T rows[PM_TJ * (PM_DMAX + PM_PMAX)];
+  const int tid = threadIdx.x;
+  const int W = D + P;
+  constexpr int RS = PM_DMAX + PM_PMAX;   // fixed row stride: [x(16) | alpha(16)]
+  T xq[PM_QPT][PM_DMAX];
+  T acc[PM_QPT][PM_PMAX];
+  long long qm[PM_QPT];
+#pragma unroll
+  for (int q = 0; q < PM_QPT; ++q) {
+    qm[q] = ((long long)blockIdx.x * PM_QPT + q) * 256 + tid;
+#pragma unroll
+    for (int d = 0; d < PM_DMAX; ++d) {
+      xq[q][d] = T(0);
+      if (d < D && qm[q] < M) xq[q][d] = Xq[qm[q] * D + d] / T(ls.v[d]);
+    }
+#pragma unroll
+    for (int p = 0; p < PM_PMAX; ++p) acc[q][p] = T(0);
+  }
+  const long long n0 = (long long)blockIdx.y * chunk;
+  const long long n1 = min(N, n0 + chunk);
+  for (long long jb = n0; jb < n1; jb += PM_TJ) {
+    const int nj = (int)min((long long)PM_TJ, n1 - jb);
+    __syncthreads();
+    for (int e = tid; e < nj * W; e += 256) {
+      const int j = e / W, c = e - j * W;
+      if (c < D) rows[j * RS + c] = X[(jb + j) * D + c] / T(ls.v[c]);
+      else rows[j * RS + PM_DMAX + (c - D)] = alpha[(jb + j) * P + (c - D)];
+    }
+    __syncthreads();
+    for (int j = 0; j < nj; ++j) {
+      const T* row = rows + j * RS;
+      T d2[PM_QPT];
+#pragma unroll
+      for (int q = 0; q < PM_QPT; ++q) d2[q] = T(0);
+#pragma unroll
+      for (int d = 0; d < PM_DMAX; ++d) {
+        if (d < D) {
+          const T xt = row[d];
+#pragma unroll
+          for (int q = 0; q < PM_QPT; ++q) {
+            const T df = xq[q][d] - xt;
+            d2[q] = __builtin_fma(df, df, d2[q]);
+          }
+        }
+      }
+      T e[PM_QPT];
+#pragma unroll
+      for (int q = 0; q < PM_QPT; ++q) e[q] = exp_neg(T(-0.5) * d2[q]);
+#pragma unroll
+      for (int p = 0; p < PM_PMAX; ++p) {
+        if (p < P) {
+          const T a = row[PM_DMAX + p];
+#pragma unroll
+          for (int q = 0; q < PM_QPT; ++q) acc[q][p] = __builtin_fma(e[q], a, acc[q][p]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PM_QPT; ++q) {
+    if (qm[q] < M) {
+#pragma unroll
+      for (int p = 0; p < PM_PMAX; ++p)
+        if (p < P) partial[((long long)blockIdx.y * M + qm[q]) * P + p] = acc[q][p];
+    }
+  }
+}
+
+template <typename T>
+__global__ void mean_reduce_kernel(const T* __restrict__ partial, int S, long long M, int P, T sf2, PArr ymean,
+                                   PArr ystd, T* __restrict__ mean) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * P) return;
+  const int p = (int)(e % P);
+  T s = T(0);
+  for (int k = 0; k < S; ++k) s += partial[(long long)k * M * P + e];
+  mean[e] = T(ymean.v[p]) + T(ystd.v[p]) * (sf2 * s);
+}
+
+// ---- column sums of squares (fp64 accumulation) -------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsumsq_kernel(const T* __restrict__ B, long long rows_per, long long Np,
+                                                       long long ldb, double* __restrict__ partial, long long Mp) {
+  // 128 columns per workgroup; the two thread halves take alternate rows
+  const int c = threadIdx.x & 127, hh = threadIdx.x >> 7;
+  const long long m = (long long)blockIdx.x * 128 + c;
+  const long long r0 = (long long)blockIdx.y * rows_per, r1 = min(Np, r0 + rows_per);
+  double s0 = 0.0, s1 = 0.0;
+  long long r = r0 + hh;
+  for (; r + 2 < r1; r += 4) {
+    const double a = (double)B[r * ldb + m], b = (double)B[(r + 2) * ldb + m];
+    s0 = __builtin_fma(a, a, s0);
+    s1 = __builtin_fma(b, b, s1);
+  }
+  if (r < r1) { const double a = (double)B[r * ldb + m]; s0 = __builtin_fma(a, a, s0); }
+  partial[((long long)blockIdx.y * 2 + hh) * Mp + m] = s0 + s1;
+}
+__global__ void colsum_reduce_kernel(const double* __restrict__ partial, int S, long long Mp,
+                                     double* __restrict__ out) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mp) return;
+  double s = 0.0;
+  for (int k = 0; k < S; ++k) s += partial[(long long)k * Mp + m];
+  out[m] = s;
+}
+__global__ void var_finalize_kernel(const double* ss, long long M, double kss, double floor_, double* var) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  var[m] = fmax(kss - ss[m], floor_);
+}
+
+int fill_ls(gpk_handle h, const double* ls, int D, LsArr& out) {
+  GPK_REQUIRE(h, D >= 1 && D <= GPK_MAX_D, "D must be in [1, 64]");
+  GPK_REQUIRE(h, ls != nullptr, "length-scale array is null");
+  for (int d = 0; d < GPK_MAX_D; ++d) out.v[d] = 1.0;
+  for (int d = 0; d < D; ++d) {
+    GPK_REQUIRE(h, ls[d] > 0.0, "length-scales must be positive");
+    out.v[d] = ls[d];
+  }
+  return GPK_OK;
+}
+
+}  // namespace
+
+extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls, double sf2,
+                        double diag_add, void* K, int64_t ldk) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, N >= 1 && X && K, "gram: null pointer or N < 1");
+  const int64_t Np = gpk_padded(N);
+  GPK_REQUIRE(h, ldk >= Np && ldk % 2 == 0, "gram: ldk must be >= gpk_padded(N)");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "gram: bad dtype");
+  LsArr l;
+  GPK_TRY(fill_ls(h, ls, D, l));
+  const int64_t nt = Np / TS;
+  const int64_t tiles = nt * (nt + 1) / 2;
+  GPK_REQUIRE(h, tiles < (1ll << 31), "gram: N too large");
+  const bool stream_nt = Np >= 16384;   // streaming stores once K exceeds the caches
+  GPK_REQUIRE(h, ((uintptr_t)K % 16) == 0, "gram: K must be 16-byte aligned");
+  const dim3 grid((unsigned)tiles), block(256);
+#define GPK_GRAM_LAUNCH(T, NT)                                                                          \
+  hipLaunchKernelGGL((gram_sym_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
+                     (T)sf2, (T)diag_add, (T*)K, (long long)ldk)
+  if (dtype == GPK_F64) { if (stream_nt) GPK_GRAM_LAUNCH(double, true); else GPK_GRAM_LAUNCH(double, false); }
+  else { if (stream_nt) GPK_GRAM_LAUNCH(float, true); else GPK_GRAM_LAUNCH(float, false); }
+#undef GPK_GRAM_LAUNCH
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t N, const void* Xq, int64_t M,
+                                int D, const double* ls, double sf2, void* B, int64_t ldb) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && X && Xq && B, "cross_gram: null pointer or empty input");
+  const int64_t Np = gpk_padded(N), Mp = gpk_padded(M);
+  GPK_REQUIRE(h, ldb >= Mp && ldb % 4 == 0, "cross_gram: ldb must be >= gpk_padded(M)");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "cross_gram: bad dtype");
+  LsArr l;
+  GPK_TRY(fill_ls(h, ls, D, l));
+  dim3 grid((unsigned)(Mp / TS), (unsigned)(Np / TS));
+  GPK_REQUIRE(h, Np / TS < 65536, "cross_gram: N too large");
+  if (dtype == GPK_F64)
+    hipLaunchKernelGGL(cross_t_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)X, (long long)N,
+                       (const double*)Xq, (long long)M, D, l, sf2, (double*)B, (long long)ldb);
+  else
+    hipLaunchKernelGGL(cross_t_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)X, (long long)N,
+                       (const float*)Xq, (long long)M, D, l, (float)sf2, (float*)B, (long long)ldb);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D, int P,
+                                const double* ls, double sf2, const double* y_mean, const double* y_std,
+                                const void* Xq, int64_t M, void* mean) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && alpha && Xq && mean && y_mean && y_std, "predict_mean: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1, "predict_mean: empty input");
+  GPK_REQUIRE(h, D >= 1 && D <= PM_DMAX, "predict_mean: D must be in [1, 16]");
+  GPK_REQUIRE(h, P >= 1 && P <= PM_PMAX, "predict_mean: P must be in [1, 16]");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "predict_mean: bad dtype");
+  LsArr l;
+  GPK_TRY(fill_ls(h, ls, D, l));
+  PArr ym{}, ys{};
+  for (int p = 0; p < P; ++p) { ym.v[p] = y_mean[p]; ys.v[p] = y_std[p]; }
+  Ls16 l16;
+  for (int d = 0; d < 16; ++d) l16.v[d] = l.v[d];
+  const int64_t nqb = (M + 256 * PM_QPT - 1) / (256 * PM_QPT);
+  // split the training set so that the grid has >= ~2048 workgroups (8 per CU)
+  int64_t S = (2048 + nqb - 1) / nqb;
+  const int64_t maxS = (N + PM_TJ - 1) / PM_TJ;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  if (S > 65535) S = 65535;
+  int64_t chunk = (N + S - 1) / S;
+  chunk = (chunk + PM_TJ - 1) / PM_TJ * PM_TJ;
+  S = (N + chunk - 1) / chunk;
+  const size_t es = dtype == GPK_F64 ? 8 : 4;
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)S * M * P * es, &partial));
+  dim3 grid((unsigned)nqb, (unsigned)S);
+  const int64_t tot = M * P;
+  if (dtype == GPK_F64) {
+    hipLaunchKernelGGL(predict_mean_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)X,
+                       (const double*)alpha, (long long)N, D, P, l16, (const double*)Xq, (long long)M,
+                       (long long)chunk, (double*)partial);
+    GPK_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(mean_reduce_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double*)partial, (int)S, (long long)M, P, sf2, ym, ys, (double*)mean);
+  } else {
+    hipLaunchKernelGGL(predict_mean_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)X,
+                       (const float*)alpha, (long long)N, D, P, l16, (const float*)Xq, (long long)M,
+                       (long long)chunk, (float*)partial);
+    GPK_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(mean_reduce_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float*)partial, (int)S, (long long)M, P, (float)sf2, ym, ys, (float*)mean);
+  }
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, int64_t Mp, int64_t ldb,
+                            double* out) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, B && out, "colsumsq: null pointer");
+  GPK_REQUIRE(h, Np > 0 && Mp > 0 && Mp % 128 == 0 && ldb >= Mp, "colsumsq: Mp must be a multiple of 128");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "colsumsq: bad dtype");
+  const int64_t nmb = Mp / 128;
+  int64_t S = (2048 + nmb - 1) / nmb;
+  if (S > Np / 64) S = Np / 64;
+  if (S < 1) S = 1;
+  if (S > 32768) S = 32768;
+  const int64_t rows_per = (Np + S - 1) / S;
+  S = (Np + rows_per - 1) / rows_per;
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)2 * S * Mp * sizeof(double), &partial));
+  dim3 grid((unsigned)nmb, (unsigned)S);
+  if (dtype == GPK_F64)
+    hipLaunchKernelGGL(colsumsq_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)B,
+                       (long long)rows_per, (long long)Np, (long long)ldb, (double*)partial, (long long)Mp);
+  else
+    hipLaunchKernelGGL(colsumsq_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)B, (long long)rows_per,
+                       (long long)Np, (long long)ldb, (double*)partial, (long long)Mp);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, h->stream,
+                     (const double*)partial, (int)(2 * S), (long long)Mp, out);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var) {
+  hipLaunchKernelGGL(var_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, ss,
+                     (long long)M, kss, floor_, var);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}

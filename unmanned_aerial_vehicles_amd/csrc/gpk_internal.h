@@ -1,0 +1,90 @@
+// Internal declarations shared by the libgpk translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/gpk.h"
+
+struct gpk_context {
+  int device = 0;
+  hipStream_t stream = nullptr;      // stream kernels are launched on
+  hipStream_t own_stream = nullptr;  // created by gpk_create
+  bool user_stream = false;
+  std::string err;
+  // growable device scratch owned by the handle (small / medium temporaries)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  int* d_info = nullptr;        // device int for potrf pivot failures
+  double* d_small = nullptr;    // 4 KiB device doubles for reductions
+  double* h_small = nullptr;    // pinned host mirror
+};
+
+#define GPK_CHECK_HIP(h, call)                                                          \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+      return GPK_HIP_ERROR;                                                             \
+    }                                                                                   \
+  } while (0)
+
+#define GPK_REQUIRE(h, cond, msg)                                                       \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      (h)->err = std::string("bad argument: ") + (msg);                                 \
+      return GPK_BAD_ARG;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define GPK_LAUNCH_CHECK(h)                                                             \
+  do {                                                                                  \
+    hipError_t e_ = hipGetLastError();                                                  \
+    if (e_ != hipSuccess) {                                                             \
+      (h)->err = std::string("kernel launch: ") + hipGetErrorString(e_);                \
+      return GPK_HIP_ERROR;                                                             \
+    }                                                                                   \
+  } while (0)
+
+#define GPK_TRY(expr)                                                                   \
+  do {                                                                                  \
+    int rc_ = (expr);                                                                   \
+    if (rc_ != GPK_OK) return rc_;                                                      \
+  } while (0)
+
+int gpk_scratch(gpk_handle h, size_t bytes, void** out);
+
+// ---- dense GEMM on MFMA (gpk_gemm.hip) ---------------------------------------------
+// C[m x n] = alpha * opA(A) * opB(B)^T + beta * C on whole 128x128 tiles.
+//   ta == 0: A stored (m x k), k contiguous;  ta == 1: A stored (k x m), m contiguous.
+//   tb == 0: B stored (n x k), k contiguous;  tb == 1: B stored (k x n), n contiguous.
+// m, n multiples of 128; k multiple of 16.  lower_only skips tiles strictly above the
+// diagonal.  Per-tile k range: [kb0 + kb_row * tile_row + kb_col * tile_col,
+// ke0 + ke_row * tile_row + ke_col * tile_col) clipped to [0, k) (ke0 < 0 means "k").
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  int64_t lda, ldb, ldc;
+  int m, n, k;
+  int ta, tb;
+  double alpha, beta;
+  int lower_only;
+  int kb0, kb_row, kb_col, ke0, ke_row, ke_col;
+  int heavy_first;  // reverse tile-row order (triangular work: longest first)
+};
+inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb,
+                          void* C, int64_t ldc, int m, int n, int k, double alpha, double beta) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.m = m; g.n = n; g.k = k; g.ta = ta; g.tb = tb; g.alpha = alpha; g.beta = beta;
+  g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0;
+  g.heavy_first = 0;
+  return g;
+}
+int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);
+
+int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);

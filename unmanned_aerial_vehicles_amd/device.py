@@ -1,0 +1,317 @@
+"""Device-side GP model: owns the HBM buffers (as torch tensors — torch is used for device
+memory and streams only) and drives the HIP kernels through the libgpk C ABI.
+
+Layout in HBM (row-major, Np = N rounded up to 128, identity in the padding):
+    X      (N, D)   f64   training inputs                     [+ f32 copy for the fp32 predict path]
+    Yn     (N, P)   f64   normalised targets
+    K / L  (Np, Np) f64   Gram matrix, overwritten in place by its lower Cholesky factor
+    winv   (Np,128) f64   inverses of the 128x128 diagonal blocks of L
+    alpha  (N, P)   f64   K^-1 Yn
+    Lf, winvf, alphaf     f32 copies, built on the first fp32 predict
+    Kinv, W (Np, Np) f64  only while hyper-parameter gradients are being evaluated
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import GPK_F32, GPK_F64, GPKError, NotPositiveDefinite
+
+_backends = {}
+_backends_lock = threading.Lock()
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Backend:
+    """One libgpk handle per GPU, bound to torch's current stream on that device."""
+
+    def __init__(self, device_index=0):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the GP kernels need an MI355X (there is no CPU fallback)")
+        self.device_index = int(device_index)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.gpk_create(C.byref(h), self.device_index)
+        if rc != _lib.GPK_OK:
+            raise GPKError(rc, "gpk_create failed")
+        self.h = h
+        self.lock = threading.RLock()
+        self.bind_stream()
+
+    def bind_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.check(self.lib.gpk_set_stream(self.h, C.c_void_p(s)))
+
+    def check(self, rc):
+        if rc == _lib.GPK_OK:
+            return
+        msg = self.lib.gpk_last_error(self.h).decode()
+        if rc == _lib.GPK_NOT_PD:
+            raise NotPositiveDefinite(msg)
+        raise GPKError(rc, msg)
+
+    def sync(self):
+        self.check(self.lib.gpk_synchronize(self.h))
+
+    def empty(self, shape, dtype):
+        return _torch().empty(shape, dtype=dtype, device=self.device)
+
+    def upload(self, a, dtype=None):
+        torch = _torch()
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+
+def get_backend(device_index=None) -> Backend:
+    torch = _torch()
+    if device_index is None:
+        device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    with _backends_lock:
+        b = _backends.get(device_index)
+        if b is None:
+            b = _backends[device_index] = Backend(device_index)
+        return b
+
+
+def padded(n):
+    return (int(n) + 127) // 128 * 128
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class DeviceGP:
+    """Training set + factorisation resident on one GPU."""
+
+    # largest scratch (bytes) used for one variance panel  V = L^-1 K*^T
+    VAR_PANEL_BYTES = 6 << 30
+    VAR_PANEL_MAX = 16384
+
+    def __init__(self, X, Yn, backend: Backend | None = None):
+        torch = _torch()
+        self.be = backend or get_backend()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Yn = np.ascontiguousarray(Yn, dtype=np.float64)
+        if X.ndim != 2 or Yn.ndim != 2 or X.shape[0] != Yn.shape[0]:
+            raise ValueError("X must be (N, D) and Y (N, P)")
+        self.N, self.D = X.shape
+        self.P = Yn.shape[1]
+        if not (1 <= self.D <= _lib.GPK_MAX_D):
+            raise ValueError(f"D must be in [1, {_lib.GPK_MAX_D}]")
+        if not (1 <= self.P <= _lib.GPK_MAX_P):
+            raise ValueError(f"P must be in [1, {_lib.GPK_MAX_P}]")
+        self.Np = padded(self.N)
+        self.X = self.be.upload(X)
+        self.Yn = self.be.upload(Yn)
+        self.K = None       # (Np, Np) f64: Gram, then L
+        self.winv = None
+        self.alpha = self.be.empty((self.N, self.P), torch.float64)
+        self.factored = False
+        self.ls = None
+        self.sf2 = None
+        self._f32 = None    # (Xf, alphaf, Lf, winvf)
+        self._Kinv = None
+        self._W = None
+
+    # ---- fit-side -------------------------------------------------------------------------
+    def _ensure_K(self):
+        torch = _torch()
+        if self.K is None:
+            self.K = self.be.empty((self.Np, self.Np), torch.float64)
+            self.winv = self.be.empty((self.Np, 128), torch.float64)
+
+    def gram(self, ls, sf2, diag_add):
+        """K1: build the padded Gram matrix in HBM."""
+        self._ensure_K()
+        ls = np.ascontiguousarray(np.broadcast_to(np.asarray(ls, dtype=np.float64), (self.D,)))
+        be = self.be
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_gram(be.h, GPK_F64, _p(self.X), self.N, self.D, ls.ctypes.data_as(_lib._dp),
+                                     float(sf2), float(diag_add), _p(self.K), self.Np))
+        self.ls, self.sf2 = ls, float(sf2)
+        self.factored = False
+        self._f32 = None
+
+    def factorize(self, ls, sf2, diag_add):
+        """K1 + K2: Gram build and in-place blocked Cholesky.  Raises NotPositiveDefinite."""
+        self.gram(ls, sf2, diag_add)
+        be = self.be
+        info = C.c_int(0)
+        with be.lock:
+            be.check(be.lib.gpk_potrf(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), C.byref(info)))
+        self.factored = True
+
+    def load_factor(self, L, ls, sf2):
+        """Import an existing lower factor (host, N x N), e.g. from a scikit-learn pickle."""
+        torch = _torch()
+        self._ensure_K()
+        L = np.asarray(L, dtype=np.float64)
+        Kh = torch.eye(self.Np, dtype=torch.float64)
+        Kh[: self.N, : self.N] = torch.from_numpy(np.tril(L))
+        self.K.copy_(Kh)
+        be = self.be
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_leaf_inverses(be.h, _p(self.K), self.Np, self.Np, _p(self.winv)))
+        self.ls = np.ascontiguousarray(np.broadcast_to(np.asarray(ls, dtype=np.float64), (self.D,)))
+        self.sf2 = float(sf2)
+        self.factored = True
+        self._f32 = None
+
+    def solve_alpha(self):
+        """K3: alpha = L^-T L^-1 Yn."""
+        assert self.factored
+        be = self.be
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_potrs(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self.Yn), self.N,
+                                      self.P, _p(self.alpha)))
+        self._f32 = None
+
+    def set_alpha(self, alpha):
+        self.alpha.copy_(self.be.upload(np.asarray(alpha, dtype=np.float64).reshape(self.N, self.P)))
+        self._f32 = None
+
+    def lml_terms(self):
+        """K6a: (sum log diag L, [y_p . alpha_p])."""
+        be = self.be
+        out = np.zeros(1 + self.P)
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_lml_terms(be.h, _p(self.K), self.N, self.Np, _p(self.Yn), _p(self.alpha), self.P,
+                                          out.ctypes.data_as(_lib._dp)))
+        return out[0], out[1:]
+
+    def lml_grad(self, noise):
+        """K6b: [dLML/dlog ls_d ..., dLML/dlog noise, dLML/dlog sf2] at the current factor/alpha."""
+        torch = _torch()
+        assert self.factored
+        if self.D > 16:
+            raise ValueError("analytic LML gradients support D <= 16")
+        if self._Kinv is None:
+            self._Kinv = self.be.empty((self.Np, self.Np), torch.float64)
+            self._W = self.be.empty((self.Np, self.Np), torch.float64)
+        be = self.be
+        g = np.zeros(self.D + 2)
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_potri(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self._Kinv), self.Np,
+                                      _p(self._W)))
+            be.check(be.lib.gpk_lml_grad(be.h, _p(self.X), self.N, self.D, self.ls.ctypes.data_as(_lib._dp),
+                                         self.sf2, float(noise), _p(self.alpha), self.P, _p(self._Kinv), self.Np,
+                                         g.ctypes.data_as(_lib._dp)))
+        return g
+
+    def release_grad_buffers(self):
+        self._Kinv = None
+        self._W = None
+
+    # ---- host views ------------------------------------------------------------------------
+    def L_host(self):
+        return np.tril(self.K[: self.N, : self.N].cpu().numpy())
+
+    def alpha_host(self):
+        return self.alpha.cpu().numpy()
+
+    # ---- predict-side ----------------------------------------------------------------------
+    def _f32_copies(self):
+        torch = _torch()
+        if self._f32 is None:
+            be = self.be
+            Xf = self.X.to(torch.float32)
+            af = self.alpha.to(torch.float32)
+            Lf = be.empty((self.Np, self.Np), torch.float32)
+            wf = be.empty((self.Np, 128), torch.float32)
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_factor_to_f32(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(Lf),
+                                                  self.Np, _p(wf)))
+            self._f32 = (Xf, af, Lf, wf)
+        return self._f32
+
+    def _as_queries(self, Xq, tdtype):
+        torch = _torch()
+        if isinstance(Xq, torch.Tensor):
+            q = Xq.to(device=self.be.device, dtype=tdtype).contiguous()
+        else:
+            q = self.be.upload(np.ascontiguousarray(Xq, dtype=np.float64), tdtype)
+        if q.ndim != 2 or q.shape[1] != self.D:
+            raise ValueError(f"queries must be (M, {self.D})")
+        return q
+
+    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64"):
+        """K4 on device tensors; returns a (M, P) tensor of `dtype`."""
+        torch = _torch()
+        f32 = dtype in ("float32", np.float32, torch.float32)
+        tdt = torch.float32 if f32 else torch.float64
+        q = self._as_queries(Xq, tdt)
+        M = q.shape[0]
+        out = self.be.empty((M, self.P), tdt)
+        if M == 0:
+            return out
+        if f32:
+            Xd, ad = self._f32_copies()[:2]
+        else:
+            Xd, ad = self.X, self.alpha
+        ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
+        ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
+        be = self.be
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_predict_mean(be.h, GPK_F32 if f32 else GPK_F64, _p(Xd), _p(ad), self.N, self.D,
+                                             self.P, self.ls.ctypes.data_as(_lib._dp), self.sf2,
+                                             ym.ctypes.data_as(_lib._dp), ys.ctypes.data_as(_lib._dp), _p(q), M,
+                                             _p(out)))
+        return out
+
+    def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64"):
+        """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units)."""
+        torch = _torch()
+        assert self.factored
+        f32 = dtype in ("float32", np.float32, torch.float32)
+        tdt = torch.float32 if f32 else torch.float64
+        es = 4 if f32 else 8
+        q = self._as_queries(Xq, tdt)
+        M = q.shape[0]
+        out = self.be.empty((M,), torch.float64)
+        if M == 0:
+            return out
+        if f32:
+            Xd, _, Ld, wd = self._f32_copies()
+        else:
+            Xd, Ld, wd = self.X, self.K, self.winv
+        panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * es)) // 128 * 128))
+        panel = min(panel, padded(M))
+        work = self.be.empty((self.Np * panel,), tdt)
+        var = self.be.empty((panel,), torch.float64)
+        be = self.be
+        with be.lock:
+            be.bind_stream()
+            for m0 in range(0, M, panel):
+                m1 = min(M, m0 + panel)
+                be.check(be.lib.gpk_predict_var(be.h, GPK_F32 if f32 else GPK_F64, _p(Xd), self.N, self.D,
+                                                self.ls.ctypes.data_as(_lib._dp), self.sf2, _p(Ld), self.Np,
+                                                self.Np, _p(wd), _p(q[m0:m1]), m1 - m0, float(kss), float(floor),
+                                                _p(work), _p(var)))
+                out[m0:m1].copy_(var[: m1 - m0])
+        return out
+
+    def gram_host(self, ls, sf2, diag_add):
+        """Debug/inspection helper: the (N, N) Gram matrix as a host array (overwrites the factor)."""
+        self.gram(ls, sf2, diag_add)
+        return self.K[: self.N, : self.N].cpu().numpy()

@@ -1,0 +1,222 @@
+"""`GaussianProcess` of the `quadrotor_gp_mpc` ROS package, on MI355X.
+
+Mirrors the non-ROS surface of `quadrotor_gp_mpc/quadrotor_gp_mpc/gaussian_process.py:63-394`
+(`add_training_data`, `fit`, `predict`, `log_marginal_likelihood`, `optimize_hyperparameters`,
+`train_gp`, `save_model`, `load_model`, attributes `kernel.length_scale`,
+`kernel.signal_variance`, `noise_variance`, `X_train`, `Y_train`, `L`, `alpha`).  The
+`rclpy.Node` base class and the topic callbacks stay in the caller: a node wraps this object.
+
+Semantics kept from the reference: no target normalisation; K = sf2 exp(-d2 / (2 l^2)) + noise I;
+predictive variance = sf2 - |L^-1 k*|^2 (no noise term), floored at 1e-10 and tiled over the
+outputs; not-PD fit -> noise x10 (reset to 0.01 above 1.0), alpha = 0, L = None; unfitted predict
+-> (zeros, sf2 * ones).  Squared distances use exact differences on the GPU rather than the
+reference's norm expansion (`:38`); the two differ by ~3e-14 on the flight data.
+
+Thread-safety: `fit()` builds a fresh device model and swaps it in atomically, so a predict running
+on another executor thread keeps using the previous factor (the reference shares state unlocked,
+`quadrotor_gp_mpc/quadrotor_gp_mpc/main.py:818-826`).
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+import scipy.optimize
+
+from ._lib import NotPositiveDefinite
+from .device import DeviceGP, get_backend
+
+LOG_2PI = float(np.log(2.0 * np.pi))
+
+
+class RBFKernel:
+    """Hyper-parameter holder (gaussian_process.py:19-24)."""
+
+    def __init__(self, length_scale=1.0, signal_variance=1.0):
+        self.length_scale = length_scale
+        self.signal_variance = signal_variance
+
+
+class _Logger:
+    def __getattr__(self, _name):
+        return lambda *a, **k: None
+
+
+class GaussianProcess:
+    def __init__(self, input_dim=16, output_dim=12, device=None, predict_dtype="float64", logger=None):
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.kernel = RBFKernel(length_scale=1.0, signal_variance=1.0)
+        self.noise_variance = 0.01
+        self.X_train = np.empty((0, input_dim))
+        self.Y_train = np.empty((0, output_dim))
+        self.K_inv = None
+        self.L = None
+        self.alpha = None
+        self.max_data_points = 1000
+        self.data_collection_active = True
+        self.device = device
+        self.predict_dtype = predict_dtype
+        self._logger = logger or _Logger()
+        self._model = None          # (DeviceGP, sf2) snapshot used by predict
+        self._swap = threading.Lock()
+
+    def get_logger(self):
+        return self._logger
+
+    # ---- data (gaussian_process.py:126-156) ---------------------------------------------------
+    def add_training_data(self, X, Y):
+        X = np.atleast_2d(X)
+        Y = np.atleast_2d(Y)
+        if X.shape[1] != self.input_dim or Y.shape[1] != self.output_dim:
+            self.get_logger().error(f"Data dimension mismatch: X={X.shape}, Y={Y.shape}")
+            return
+        self.X_train = np.vstack([self.X_train, X])
+        self.Y_train = np.vstack([self.Y_train, Y])
+        if len(self.X_train) > self.max_data_points:      # FIFO eviction
+            excess = len(self.X_train) - self.max_data_points
+            self.X_train = self.X_train[excess:]
+            self.Y_train = self.Y_train[excess:]
+        self.K_inv = None
+        self.L = None
+        self.alpha = None
+
+    # ---- fit (gaussian_process.py:173-201) -----------------------------------------------------
+    def _factor(self, length_scale, signal_variance, noise_variance):
+        dev = DeviceGP(self.X_train, self.Y_train, get_backend(self.device))
+        dev.factorize(float(length_scale), float(signal_variance), float(noise_variance))
+        dev.solve_alpha()
+        return dev
+
+    def fit(self):
+        if len(self.X_train) < 2:
+            self.get_logger().warning("Insufficient training data for GP fitting")
+            return
+        try:
+            dev = self._factor(self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance)
+            with self._swap:
+                self._model = (dev, float(self.kernel.signal_variance))
+            self.alpha = dev.alpha_host()
+            self.L = _LazyFactor(dev)
+        except NotPositiveDefinite as e:
+            self.get_logger().error(f"Numerical error in GP fitting: {e}")
+            self.noise_variance *= 10
+            if self.noise_variance > 1.0:
+                self.noise_variance = 0.01
+            self.alpha = np.zeros((len(self.X_train), self.output_dim))
+            self.L = None
+            with self._swap:
+                self._model = None
+
+    # ---- predict (gaussian_process.py:203-241) ---------------------------------------------------
+    def predict(self, X_test):
+        X_test = np.atleast_2d(X_test)
+        prior = (np.zeros((len(X_test), self.output_dim)),
+                 np.ones((len(X_test), self.output_dim)) * self.kernel.signal_variance)
+        if len(self.X_train) == 0 or self.alpha is None:
+            return prior
+        with self._swap:
+            model = self._model
+        if model is None:           # failed fit: alpha = 0, L missing -> the reference's except branch
+            return prior
+        try:
+            dev, sf2 = model
+            mean = dev.predict_mean_dev(X_test, np.zeros(dev.P), np.ones(dev.P), self.predict_dtype)
+            var = dev.predict_var_dev(X_test, sf2, 1e-10, self.predict_dtype)
+            mean = mean.double().cpu().numpy()
+            var = np.tile(var.cpu().numpy().reshape(-1, 1), (1, self.output_dim))
+            return mean, var
+        except Exception as e:  # noqa: BLE001
+            self.get_logger().error(f"Error in GP prediction: {e}")
+            return prior
+
+    # ---- LML (gaussian_process.py:243-265) --------------------------------------------------------
+    def log_marginal_likelihood(self):
+        if len(self.X_train) < 2 or self.L is None:
+            return -np.inf
+        try:
+            dev = self._model[0]
+            logdet_half, quad = dev.lml_terms()
+            n = len(self.X_train)
+            return float(-0.5 * (2.0 * logdet_half + quad.sum() + n * self.output_dim * LOG_2PI))
+        except Exception as e:  # noqa: BLE001
+            self.get_logger().error(f"Error computing log marginal likelihood: {e}")
+            return -np.inf
+
+    # ---- hyper-parameters (gaussian_process.py:267-324) ----------------------------------------------
+    def optimize_hyperparameters(self, use_gradient=True):
+        """L-BFGS-B over log(length_scale, signal_variance, noise_variance), maxiter 50.  The
+        reference differentiates numerically (each evaluation = one full fit); here the analytic
+        gradient from the fused K6b kernel is used unless `use_gradient=False`."""
+        if len(self.X_train) < 10:
+            return
+        n, P = len(self.X_train), self.output_dim
+
+        def objective(params):
+            ls, sf2, noise = np.exp(params)
+            try:
+                dev = DeviceGP(self.X_train, self.Y_train, get_backend(self.device))
+                dev.factorize(ls, sf2, noise)
+                dev.solve_alpha()
+                logdet_half, quad = dev.lml_terms()
+            except NotPositiveDefinite:
+                return (1e6, np.zeros(3)) if use_gradient else 1e6
+            nll = 0.5 * (2.0 * logdet_half + quad.sum() + n * P * LOG_2PI)
+            if not np.isfinite(nll):
+                return (1e6, np.zeros(3)) if use_gradient else 1e6
+            if not use_gradient:
+                return float(nll)
+            g = dev.lml_grad(noise)                       # d LML / d log [ls_d..., noise, sf2]
+            D = self.X_train.shape[1]
+            grad = -np.array([np.sum(g[:D]), g[D + 1], g[D]])
+            return float(nll), grad
+
+        x0 = np.log([self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance])
+        try:
+            result = scipy.optimize.minimize(objective, x0, method="L-BFGS-B", jac=bool(use_gradient),
+                                             options={"maxiter": 50})
+            if result.success:
+                self.kernel.length_scale = float(np.exp(result.x[0]))
+                self.kernel.signal_variance = float(np.exp(result.x[1]))
+                self.noise_variance = float(np.exp(result.x[2]))
+                self.fit()
+        except Exception as e:  # noqa: BLE001
+            self.get_logger().error(f"Hyperparameter optimization failed: {e}")
+
+    def train_gp(self):
+        """Periodic training callback (gaussian_process.py:360-367)."""
+        if len(self.X_train) >= 10:
+            if len(self.X_train) % 50 == 0:
+                self.optimize_hyperparameters()
+            else:
+                self.fit()
+
+    # ---- persistence (gaussian_process.py:369-394) ---------------------------------------------------
+    def save_model(self, filename):
+        np.savez(filename, X_train=self.X_train, Y_train=self.Y_train, length_scale=self.kernel.length_scale,
+                 signal_variance=self.kernel.signal_variance, noise_variance=self.noise_variance)
+
+    def load_model(self, filename):
+        try:
+            data = np.load(filename)
+            self.X_train = data["X_train"]
+            self.Y_train = data["Y_train"]
+            self.kernel.length_scale = float(data["length_scale"])
+            self.kernel.signal_variance = float(data["signal_variance"])
+            self.noise_variance = float(data["noise_variance"])
+            self.fit()
+        except Exception as e:  # noqa: BLE001
+            self.get_logger().error(f"Failed to load GP model: {e}")
+
+
+class _LazyFactor:
+    """`gp.L` placeholder: truthy once fitted, materialises the (N, N) host copy on demand."""
+
+    def __init__(self, dev):
+        self._dev = dev
+        self._host = None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._host is None:
+            self._host = self._dev.L_host()
+        return self._host if dtype is None else self._host.astype(dtype)

@@ -1,0 +1,166 @@
+"""Per-output ARD GP trainer / loader — the reference's alternative offline trainer on MI355X.
+
+`GPTrainer.train_gp_models` mirrors `src/px4/gp_trainer.py:121-205`: 80/20 split with seed 42,
+one independent GP per residual component, z-scored inputs and target,
+`C(1, fixed) * RBF(ls in R^D, bounds 0.1..10) + WhiteKernel(0.01, 1e-5..10)`, `alpha=1e-6`,
+3 optimiser restarts.  `PreTrainedGP.predict_residual` mirrors `src/px4/pretrained_gp.py:52-98`
+(returns the *standard deviation*, un-scaled by the target scaler), plus a batched variant.
+The pickle layout `{'gp_models','scalers_X','scalers_y','training_stats','model_name',
+'creation_time'}` is the reference's (`gp_trainer.py:214-221`).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import time
+from datetime import datetime
+
+import numpy as np
+
+from .gpr import GaussianProcessRegressor
+from .kernels import RBF, ConstantKernel, WhiteKernel
+
+OUTPUT_NAMES = ["x_residual", "y_residual", "z_residual", "vx_residual", "vy_residual", "vz_residual"]
+
+
+class StandardScaler:
+    """z-scoring with population std; zero scale -> 1 (what the reference gets from scikit-learn)."""
+
+    def fit(self, A):
+        A = np.asarray(A, dtype=np.float64)
+        self.mean_ = A.mean(axis=0)
+        s = A.std(axis=0)
+        self.scale_ = np.where(s < 10 * np.finfo(np.float64).eps, 1.0, s)
+        return self
+
+    def transform(self, A):
+        return (np.asarray(A, dtype=np.float64) - self.mean_) / self.scale_
+
+    def fit_transform(self, A):
+        return self.fit(A).transform(A)
+
+    def inverse_transform(self, A):
+        return np.asarray(A, dtype=np.float64) * self.scale_ + self.mean_
+
+
+def train_test_split(X, y, test_size=0.2, random_state=42):
+    """Shuffled split: permutation from RandomState(seed); the first ceil(test_size * n) indices are
+    the test set, the rest the training set (the ShuffleSplit rule the reference relies on)."""
+    n = len(X)
+    n_test = int(np.ceil(test_size * n))
+    n_train = int(np.floor((1.0 - test_size) * n))
+    perm = np.random.RandomState(random_state).permutation(n)
+    te, tr = perm[:n_test], perm[n_test:n_test + n_train]
+    return X[tr], X[te], y[tr], y[te]
+
+
+def _r2(y_true, y_pred):
+    ss_res = np.sum((y_true - y_pred) ** 2)
+    ss_tot = np.sum((y_true - np.mean(y_true)) ** 2)
+    return 1.0 - ss_res / ss_tot if ss_tot > 0 else 0.0
+
+
+class GPTrainer:
+    def __init__(self, data_dir="gp_data", model_dir="gp_models", device=None):
+        self.data_dir = data_dir
+        self.model_dir = model_dir
+        self.device = device
+        self.gp_models, self.scalers_X, self.scalers_y, self.training_stats = {}, {}, {}, {}
+
+    def train_gp_models(self, X, y, test_size=0.2, n_restarts_optimizer=3, optimizer="fmin_l_bfgs_b"):
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        X_tr, X_te, y_tr, y_te = train_test_split(X, y, test_size=test_size, random_state=42)
+        results = {}
+        for i, name in enumerate(OUTPUT_NAMES[: y.shape[1]]):
+            yi_tr, yi_te = y_tr[:, i], y_te[:, i]
+            if np.std(yi_tr) < 1e-6:          # gp_trainer.py:148-150
+                continue
+            sx, sy = StandardScaler(), StandardScaler()
+            Xs = sx.fit_transform(X_tr)
+            ys = sy.fit_transform(yi_tr.reshape(-1, 1)).flatten()
+            kernel = (ConstantKernel(1.0, constant_value_bounds="fixed")
+                      * RBF(length_scale=[1.0] * X.shape[1], length_scale_bounds=(0.1, 10.0))
+                      + WhiteKernel(noise_level=0.01, noise_level_bounds=(1e-5, 1e1)))
+            gp = GaussianProcessRegressor(kernel=kernel, n_restarts_optimizer=n_restarts_optimizer, alpha=1e-6,
+                                          normalize_y=False, optimizer=optimizer, device=self.device)
+            gp.fit(Xs, ys)
+            pred = sy.inverse_transform(gp.predict(sx.transform(X_te)).reshape(-1, 1)).flatten()
+            mse = float(np.mean((yi_te - pred) ** 2))
+            self.gp_models[name], self.scalers_X[name], self.scalers_y[name] = gp, sx, sy
+            results[name] = {"mse": mse, "rmse": float(np.sqrt(mse)), "r2": float(_r2(yi_te, pred)),
+                             "kernel": str(gp.kernel_), "log_marginal_likelihood": gp.log_marginal_likelihood()}
+        self.training_stats = results
+        return results
+
+    def save_models(self, model_name=None):
+        if model_name is None:
+            model_name = f"gp_model_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+        os.makedirs(self.model_dir, exist_ok=True)
+        path = os.path.join(self.model_dir, f"{model_name}.pkl")
+        with open(path, "wb") as f:
+            pickle.dump({"gp_models": self.gp_models, "scalers_X": self.scalers_X, "scalers_y": self.scalers_y,
+                         "training_stats": self.training_stats, "model_name": model_name,
+                         "creation_time": time.time()}, f)
+        return path
+
+    def load_models(self, model_path):
+        with open(model_path, "rb") as f:
+            d = pickle.load(f)
+        self.gp_models, self.scalers_X = d["gp_models"], d["scalers_X"]
+        self.scalers_y, self.training_stats = d["scalers_y"], d["training_stats"]
+
+
+class PreTrainedGP:
+    def __init__(self, model_path):
+        self.model_path = model_path
+        self.gp_models, self.scalers_X, self.scalers_y, self.training_stats = {}, {}, {}, {}
+        self.is_loaded = False
+        self.load_models()
+
+    def load_models(self):
+        if not os.path.exists(self.model_path):
+            print(f"GP model file not found: {self.model_path}")
+            return False
+        try:
+            with open(self.model_path, "rb") as f:
+                d = pickle.load(f)
+            self.gp_models, self.scalers_X = d["gp_models"], d["scalers_X"]
+            self.scalers_y, self.training_stats = d["scalers_y"], d["training_stats"]
+            self.is_loaded = True
+            return True
+        except Exception as e:  # noqa: BLE001
+            print(f"Failed to load GP models: {e}")
+            return False
+
+    def predict_residual(self, state, control):
+        """One query -> (mean (6,), std (6,)); missing / failing components -> (0, 1e6)."""
+        mean, std = self.predict_residual_batch(
+            np.concatenate([np.asarray(state, float)[:6], np.asarray(control, float)[:4]]).reshape(1, -1))
+        return mean[0], std[0]
+
+    def predict_residual_batch(self, X):
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if not self.is_loaded:
+            return np.zeros((len(X), 6)), np.ones((len(X), 6)) * 1e6
+        mean = np.zeros((len(X), 6))
+        std = np.full((len(X), 6), 1e6)
+        for i, name in enumerate(OUTPUT_NAMES):
+            if name not in self.gp_models:
+                continue
+            try:
+                Xs = self.scalers_X[name].transform(X)
+                m, s = self.gp_models[name].predict(Xs, return_std=True)
+                mean[:, i] = self.scalers_y[name].inverse_transform(m.reshape(-1, 1)).flatten()
+                std[:, i] = np.abs(s * self.scalers_y[name].scale_[0])
+            except Exception as e:  # noqa: BLE001
+                print(f"GP prediction failed for {name}: {e}")
+                mean[:, i], std[:, i] = 0.0, 1e6
+        return mean, std
+
+    def get_uncertainty(self, state, control):
+        return float(np.mean(self.predict_residual(state, control)[1]))
+
+    def get_stats(self):
+        return {"is_loaded": self.is_loaded, "model_path": self.model_path,
+                "available_models": list(self.gp_models.keys()), "training_stats": self.training_stats}
