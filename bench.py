@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GP predictions/s (posterior mean + variance) at N_train = 65 536, D = 9.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], SURVEY.md §8d "C3"): synthetic N_train x 9 training set with 3
+outputs, fitted once on the GPU in fp64 (Gram build + blocked Cholesky + alpha; untimed set-up,
+reported under "fit"), then every timed step predicts mean AND variance for one batch of
+M = 10 000 query points (horizon 20 x 500 rollouts) in fp32 with the queries already resident in
+HBM.  N > 1 is weak scaling: every rank holds a replica of the model and its own 10 000-query batch
+per step, and one RCCL all-gather of the [mean | var] shards closes each step (BASELINE.json
+configs[3]).  value = predictions of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  "roofline":     fp32 MFMA roofline of the dominant kernel (the GEMM behind V = L^-1 K*^T),
+                  measured live with HIP events on the launch stream;
+  "cpu_baseline": the reference's CPU path (scikit-learn GaussianProcessRegressor, the library the
+                  reference delegates to; falls back to the repo's NumPy oracle) on a bounded sample;
+  "fit":          Gram GB/s vs the HBM roofline and Cholesky GFLOP/s of the set-up phase.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3      # dense fp32 MFMA (= fp32 vector peak)
+MFMA_F64_PEAK_TF = 78.6       # fp64 matrix peak (MI355X datasheet; used for the Cholesky fraction only)
+
+
+def synthetic_problem(N, M, D=9, P=3, qseed=1):
+    """SURVEY.md §8(d) deterministic inputs (same generator as oracle.gp_oracle.synthetic_problem)."""
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((N, D))
+    W = rng.standard_normal((D, P))
+    Y = np.sin(X @ W) + 0.1 * rng.standard_normal((N, P))
+    Xq = np.random.default_rng(qseed).standard_normal((M, D))
+    return X, Y, Xq
+
+
+def cpu_baseline(M_sample=2000, N_sample=8192):
+    """Reference CPU path on a bounded sample: fit at N_sample (untimed), then time
+    predict(return_std=True) for M_sample queries."""
+    X, Y, Xq = synthetic_problem(N_sample, M_sample)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    kind = "reference"
+    try:
+        from sklearn.gaussian_process import GaussianProcessRegressor as SkGPR
+        from sklearn.gaussian_process.kernels import RBF as SkRBF, WhiteKernel as SkWhite
+        t0 = time.perf_counter()
+        gp = SkGPR(kernel=SkRBF(2.0) + SkWhite(0.1), alpha=1e-4, normalize_y=True, optimizer=None).fit(X, Y)
+        t_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gp.predict(Xq, return_std=True)
+        t_pred = time.perf_counter() - t0
+        what = "scikit-learn GaussianProcessRegressor (the library the reference's simple_gp.py calls)"
+    except ImportError:
+        from oracle import gp_oracle as O
+        kind = "port"
+        t0 = time.perf_counter()
+        st = O.fit_fixed(X, Y, 2.0, 1.0, 0.1, 1e-4)
+        t_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.predict(st, Xq, return_std=True)
+        t_pred = time.perf_counter() - t0
+        what = "oracle/gp_oracle.py (NumPy/SciPy restatement)"
+    v = M_sample / t_pred
+    return {"value": v, "unit": "predictions/s", "cores": cores, "kind": kind,
+            "sample": f"{what}: predict(return_std=True) of {M_sample} queries at N_train={N_sample} (not 65536: the "
+                      f"CPU fit alone would take ~10 min and 100 GB); fit {t_fit:.1f} s untimed, predict {t_pred:.2f} s; "
+                      f"cost grows as N_train^2, i.e. ~{v * (N_sample / 65536.0) ** 2:.1f} predictions/s "
+                      f"extrapolated to N_train=65536",
+            "fit_seconds_at_sample": t_fit}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-train", type=int, default=65536)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from unmanned_aerial_vehicles_amd import _lib
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend, padded
+    from unmanned_aerial_vehicles_amd.sharded import all_gather_rows
+
+    be = get_backend(local_rank)
+    N, M, D, P = args.n_train, args.queries, 9, 3
+    X, Y, _ = synthetic_problem(N, 1)
+    Yn = (Y - Y.mean(0)) / Y.std(0)
+    y_mean, y_std = Y.mean(0), Y.std(0)
+    ls, sf2, noise, jitter = 2.0, 1.0, 0.1, 1e-4
+    # per-rank query batch (different seed per rank), resident in HBM before the timed region
+    Xq = np.random.default_rng(1 + rank).standard_normal((M, D))
+    q32 = torch.as_tensor(Xq, dtype=torch.float32, device=be.device)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- fit (set-up, timed separately)
+    dev = DeviceGP(X, Yn, be)
+    dev.gram(ls, sf2, noise + jitter)            # warm-up of the Gram kernel + allocation
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dev.gram(ls, sf2, noise + jitter)
+    e1.record()
+    torch.cuda.synchronize()
+    gram_s = e0.elapsed_time(e1) * 1e-3
+    gram_bytes = dev.Np * dev.Np * 8 + N * D * 8          # N^2 s + N D s (s = 8)
+    info = C.c_int(0)
+    t0 = time.perf_counter()
+    be.check(be.lib.gpk_potrf(be.h, C.c_void_p(dev.K.data_ptr()), dev.Np, dev.Np, C.c_void_p(dev.winv.data_ptr()),
+                              C.byref(info)))
+    torch.cuda.synchronize()
+    potrf_s = time.perf_counter() - t0
+    dev.factored = True
+    t0 = time.perf_counter()
+    dev.solve_alpha()
+    torch.cuda.synchronize()
+    alpha_s = time.perf_counter() - t0
+    dev._f32_factor()                              # fp32 copies of L / leaf inverses / X / alpha
+    torch.cuda.synchronize()
+    fit = {"n_train": N, "dtype": "f64",
+           "gram_ms": gram_s * 1e3, "gram_GBps": gram_bytes / gram_s / 1e9,
+           "gram_frac_of_hbm_peak": gram_bytes / gram_s / 1e9 / HBM_PEAK_GBPS,
+           "cholesky_s": potrf_s, "cholesky_GFLOPs": N ** 3 / 3.0 / potrf_s / 1e9,
+           "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
+           "alpha_solve_ms": alpha_s * 1e3}
+
+    # ---------------------------------------------------------------- the timed hot path
+    kss = sf2 + noise
+    ystd2 = torch.as_tensor(y_std ** 2, device=be.device, dtype=torch.float64)
+
+    def step():
+        mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4
+        var = dev.predict_var_dev(q32, kss, 0.0, "float32")                         # K5
+        out = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1)      # (M, 2P)
+        if world > 1:
+            out = all_gather_rows(out, M * world)                                   # RCCL all-gather
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=be.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out).all()), "non-finite predictions"
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel
+    # All GEMM launches of V = L^-1 K*^T are one kernel instantiation (gemm_kernel<float,false,true>);
+    # bracket the whole solve with HIP events on the launch stream.
+    roof = None
+    if rank == 0:
+        Mp = padded(M)
+        c = dev._f32_factor()
+        work = torch.empty((dev.Np * Mp,), dtype=torch.float32, device=be.device)
+        reps = 3
+        tot = 0.0
+        lsv = np.full(D, ls)
+        for _ in range(reps):
+            be.bind_stream()
+            be.check(be.lib.gpk_cross_gram_t(be.h, _lib.GPK_F32, C.c_void_p(c["X"].data_ptr()), N,
+                                             C.c_void_p(q32.data_ptr()), M, D, lsv.ctypes.data_as(_lib._dp), sf2,
+                                             C.c_void_p(work.data_ptr()), Mp))
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            be.check(be.lib.gpk_trsm_lower_left(be.h, _lib.GPK_F32, C.c_void_p(c["L"].data_ptr()), dev.Np, dev.Np,
+                                                C.c_void_p(c["winv"].data_ptr()), C.c_void_p(work.data_ptr()), Mp,
+                                                Mp))
+            b.record()
+            torch.cuda.synchronize()
+            tot += a.elapsed_time(b) * 1e-3
+        solve_s = tot / reps
+        flops = float(N) * float(N) * float(M)      # N^2 flops per prediction (K5)
+        n_launch = 2 * (dev.Np // 128) - 1
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<float,false,true> (all launches of the triangular solve)",
+                "achieved": flops / solve_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": flops / solve_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                "launches_per_step": n_launch, "solve_ms": solve_s * 1e3,
+                "avg_launch_ms": solve_s * 1e3 / n_launch,
+                "algorithmic_flops_per_step": flops}
+        del work
+
+    if rank == 0:
+        total_pred = float(M) * world * args.steps
+        line = {
+            "metric": "GP predictions/sec (mean+var) at N_train=65536, D=9",
+            "value": total_pred / dt, "unit": "predictions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: N_train={N}, D={D}, P={P}, batched predict mean+var over {M} query points "
+                                   f"per GPU per step (horizon 20 x 500 rollouts), fp32 predict on an fp64 factor",
+                       "n_train": N, "features": D, "outputs": P, "queries_per_gpu_per_step": M,
+                       "parallelism": f"query-sharded x{world}, model replicated" +
+                                      (", RCCL all-gather of [mean|var]" if world > 1 else "")},
+            "roofline": roof,
+            "fit": fit,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,10 @@ enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_P = 16 };
 int gpk_create(gpk_handle* h, int device);
 void gpk_destroy(gpk_handle h);
 const char* gpk_last_error(gpk_handle h);
-/* stream = hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = handle's own */
+/* Launch on `stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's
+ * default stream).  GPK_OWN_STREAM selects the non-blocking stream created by gpk_create, which is
+ * what a fresh handle uses.                                                                      */
+#define GPK_OWN_STREAM ((void*)(intptr_t)-1)
 int gpk_set_stream(gpk_handle h, void* stream);
 int gpk_synchronize(gpk_handle h);
 int64_t gpk_padded(int64_t n);

@@ -167,7 +167,15 @@ def test_package_gp(csv_data, ka, tmp_path):
     g3.fit()
     before = g3.log_marginal_likelihood()
     g3.optimize_hyperparameters()
-    assert g3.log_marginal_likelihood() > before
+    res = g3.last_optimize_result
+    assert np.isfinite(res.fun) and res.nfev >= 2
+    assert g3.log_marginal_likelihood() > before and g3.kernel.length_scale != 1.0
+    # the reference's numeric-gradient mode reaches a comparable optimum
+    g4 = GaussianProcess(input_dim=9, output_dim=3)
+    g4.max_data_points = 100
+    g4.add_training_data(X[50:150], Y[50:150])
+    g4.optimize_hyperparameters(use_gradient=False)
+    assert g4.log_marginal_likelihood() > before
 
 
 def test_pickle_and_sklearn_ingest(csv_data, ka):

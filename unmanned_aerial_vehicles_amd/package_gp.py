@@ -145,36 +145,36 @@ class GaussianProcess:
 
     # ---- hyper-parameters (gaussian_process.py:267-324) ----------------------------------------------
     def optimize_hyperparameters(self, use_gradient=True):
-        """L-BFGS-B over log(length_scale, signal_variance, noise_variance), maxiter 50.  The
-        reference differentiates numerically (each evaluation = one full fit); here the analytic
+        """L-BFGS-B over log(length_scale, signal_variance, noise_variance), maxiter 50.  As in the
+        reference every objective evaluation installs the trial hyper-parameters and refits (so after an
+        unsuccessful run the model sits at the last trial point); non-finite likelihood restores the
+        previous values and returns 1e6.  The reference differentiates numerically; here the analytic
         gradient from the fused K6b kernel is used unless `use_gradient=False`."""
         if len(self.X_train) < 10:
             return
-        n, P = len(self.X_train), self.output_dim
+        D = self.X_train.shape[1]
 
         def objective(params):
-            ls, sf2, noise = np.exp(params)
-            try:
-                dev = DeviceGP(self.X_train, self.Y_train, get_backend(self.device))
-                dev.factorize(ls, sf2, noise)
-                dev.solve_alpha()
-                logdet_half, quad = dev.lml_terms()
-            except NotPositiveDefinite:
-                return (1e6, np.zeros(3)) if use_gradient else 1e6
-            nll = 0.5 * (2.0 * logdet_half + quad.sum() + n * P * LOG_2PI)
+            old = (self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance)
+            self.kernel.length_scale = float(np.exp(params[0]))
+            self.kernel.signal_variance = float(np.exp(params[1]))
+            self.noise_variance = float(np.exp(params[2]))
+            noise = self.noise_variance
+            self.fit()
+            nll = -self.log_marginal_likelihood()
             if not np.isfinite(nll):
+                self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance = old
                 return (1e6, np.zeros(3)) if use_gradient else 1e6
             if not use_gradient:
                 return float(nll)
-            g = dev.lml_grad(noise)                       # d LML / d log [ls_d..., noise, sf2]
-            D = self.X_train.shape[1]
-            grad = -np.array([np.sum(g[:D]), g[D + 1], g[D]])
-            return float(nll), grad
+            g = self._model[0].lml_grad(noise)            # d LML / d log [ls_d..., noise, sf2]
+            return float(nll), -np.array([np.sum(g[:D]), g[D + 1], g[D]])
 
         x0 = np.log([self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance])
         try:
             result = scipy.optimize.minimize(objective, x0, method="L-BFGS-B", jac=bool(use_gradient),
                                              options={"maxiter": 50})
+            self.last_optimize_result = result
             if result.success:
                 self.kernel.length_scale = float(np.exp(result.x[0]))
                 self.kernel.signal_variance = float(np.exp(result.x[1]))
