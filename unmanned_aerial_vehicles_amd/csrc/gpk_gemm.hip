@@ -42,7 +42,7 @@ struct KParams {
   int ntm, ntn;
 };
 
-struct V16 { unsigned int x, y, z, w; };
+typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
 
 // ---- global -> registers: 4 x 16 B per thread per operand -------------------------------
 template <typename T, bool TR>
@@ -260,25 +260,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
   zero_acc(acc);
 
   if (nkt > 0) {
+    // Register-staged software pipeline ("write after the barrier"): at the top of iteration kt the
+    // registers hold k-tile kt+1 (fetched during iteration kt-1's MFMAs); they are written to the
+    // idle LDS buffer, the fetch of k-tile kt+2 is issued, and the MFMAs of k-tile kt run while it
+    // is in flight.  One barrier per k-tile; tile indices are clamped so the body is branch-free.
     V16 ra[4], rb[4];
     load_tile<T, TA>(A, p.lda, row0, kb, tid, ra);
     load_tile<T, TB>(B, p.ldb, col0, kb, tid, rb);
     store_tile<T, TA>(lds, tid, ra);
     store_tile<T, TB>(lds + LDS_OP_BYTES, tid, rb);
+    {
+      const int k1 = min(1, nkt - 1);
+      load_tile<T, TA>(A, p.lda, row0, kb + k1 * BK, tid, ra);
+      load_tile<T, TB>(B, p.ldb, col0, kb + k1 * BK, tid, rb);
+    }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int cur = kt & 1;
-      const bool more = kt + 1 < nkt;
-      if (more) {
-        load_tile<T, TA>(A, p.lda, row0, kb + (kt + 1) * BK, tid, ra);
-        load_tile<T, TB>(B, p.ldb, col0, kb + (kt + 1) * BK, tid, rb);
-      }
+      store_tile<T, TA>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
+      store_tile<T, TB>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
+      const int kn = min(kt + 2, nkt - 1);
+      load_tile<T, TA>(A, p.lda, row0, kb + kn * BK, tid, ra);
+      load_tile<T, TB>(B, p.ldb, col0, kb + kn * BK, tid, rb);
       compute_tile<TA, TB>(lds + cur * 2 * LDS_OP_BYTES, lds + cur * 2 * LDS_OP_BYTES + LDS_OP_BYTES, wm, wn,
                            lane, acc);
-      if (more) {
-        store_tile<T, TA>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
-        store_tile<T, TB>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
-      }
       __syncthreads();
     }
   }
