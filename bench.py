@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--n-train", type=int, default=65536)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--var-method", default="inverse", choices=["inverse", "solve"],
+                    help="inverse: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch (default); "
+                         "solve: blocked triangular solve chain")
     args = ap.parse_args()
 
     import torch
@@ -145,14 +148,23 @@ def main():
     dev.solve_alpha()
     torch.cuda.synchronize()
     alpha_s = time.perf_counter() - t0
-    dev._f32_factor()                              # fp32 copies of L / leaf inverses / X / alpha
+    t0 = time.perf_counter()
+    if args.var_method == "inverse":
+        dev.inverse_factor(True)                   # W = L^-1 on the fp64 MFMA, kept as fp32
+    else:
+        dev._f32_factor()                          # fp32 copies of L / leaf inverses
+    dev._f32_data()
     torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t0
     fit = {"n_train": N, "dtype": "f64",
            "gram_ms": gram_s * 1e3, "gram_GBps": gram_bytes / gram_s / 1e9,
            "gram_frac_of_hbm_peak": gram_bytes / gram_s / 1e9 / HBM_PEAK_GBPS,
            "cholesky_s": potrf_s, "cholesky_GFLOPs": N ** 3 / 3.0 / potrf_s / 1e9,
            "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
-           "alpha_solve_ms": alpha_s * 1e3}
+           "alpha_solve_ms": alpha_s * 1e3,
+           "variance_prep": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy"
+                            if args.var_method == "inverse" else "fp32 copy of L",
+           "variance_prep_s": prep_s}
 
     # ---------------------------------------------------------------- the timed hot path
     kss = sf2 + noise
@@ -160,7 +172,7 @@ def main():
 
     def step():
         mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4
-        var = dev.predict_var_dev(q32, kss, 0.0, "float32")                         # K5
+        var = dev.predict_var_dev(q32, kss, 0.0, "float32", args.var_method)        # K5
         out = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1)      # (M, 2P)
         if world > 1:
             out = all_gather_rows(out, M * world)                                   # RCCL all-gather
@@ -181,39 +193,50 @@ def main():
     assert bool(torch.isfinite(out).all()), "non-finite predictions"
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
-    # All GEMM launches of V = L^-1 K*^T are one kernel instantiation (gemm_kernel<float,false,true>);
-    # bracket the whole solve with HIP events on the launch stream.
+    # inverse: ONE launch of gemm_kernel<float,false,false,1> per step (V = W K*^T reduced to column
+    # sums of squares in its epilogue); solve: 1023 launches of gemm_kernel<float,false,true,0>.
+    # The K5 call is bracketed with HIP events on the launch stream; besides the GEMM it contains the
+    # K*-build (~1 ms) and two tiny reductions, so the figure is slightly conservative.
     roof = None
     if rank == 0:
         Mp = padded(M)
-        c = dev._f32_factor()
-        work = torch.empty((dev.Np * Mp,), dtype=torch.float32, device=be.device)
-        reps = 3
-        tot = 0.0
         lsv = np.full(D, ls)
+        lsp = lsv.ctypes.data_as(_lib._dp)
+        work = torch.empty((dev.Np * Mp,), dtype=torch.float32, device=be.device)
+        var = torch.empty((Mp,), dtype=torch.float64, device=be.device)
+        Xf = dev._f32_data()["X"]
+        reps, tot = 3, 0.0
         for _ in range(reps):
             be.bind_stream()
-            be.check(be.lib.gpk_cross_gram_t(be.h, _lib.GPK_F32, C.c_void_p(c["X"].data_ptr()), N,
-                                             C.c_void_p(q32.data_ptr()), M, D, lsv.ctypes.data_as(_lib._dp), sf2,
-                                             C.c_void_p(work.data_ptr()), Mp))
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            be.check(be.lib.gpk_trsm_lower_left(be.h, _lib.GPK_F32, C.c_void_p(c["L"].data_ptr()), dev.Np, dev.Np,
-                                                C.c_void_p(c["winv"].data_ptr()), C.c_void_p(work.data_ptr()), Mp,
-                                                Mp))
+            if args.var_method == "inverse":
+                Wf = dev.inverse_factor(True)
+                be.check(be.lib.gpk_predict_var_inv(be.h, _lib.GPK_F32, C.c_void_p(Xf.data_ptr()), N, D, lsp, sf2,
+                                                    C.c_void_p(Wf.data_ptr()), dev.Np, dev.Np,
+                                                    C.c_void_p(q32.data_ptr()), M, kss, 0.0,
+                                                    C.c_void_p(work.data_ptr()), C.c_void_p(var.data_ptr())))
+            else:
+                c = dev._f32_factor()
+                be.check(be.lib.gpk_predict_var(be.h, _lib.GPK_F32, C.c_void_p(Xf.data_ptr()), N, D, lsp, sf2,
+                                                C.c_void_p(c["L"].data_ptr()), dev.Np, dev.Np,
+                                                C.c_void_p(c["winv"].data_ptr()), C.c_void_p(q32.data_ptr()), M, kss,
+                                                0.0, C.c_void_p(work.data_ptr()), C.c_void_p(var.data_ptr())))
             b.record()
             torch.cuda.synchronize()
             tot += a.elapsed_time(b) * 1e-3
-        solve_s = tot / reps
+        k5_s = tot / reps
         flops = float(N) * float(N) * float(M)      # N^2 flops per prediction (K5)
-        n_launch = 2 * (dev.Np // 128) - 1
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<float,false,true> (all launches of the triangular solve)",
-                "achieved": flops / solve_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / solve_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                "launches_per_step": n_launch, "solve_ms": solve_s * 1e3,
-                "avg_launch_ms": solve_s * 1e3 / n_launch,
+        n_launch = 1 if args.var_method == "inverse" else 2 * (dev.Np // 128) - 1
+        roof = {"bound": "mfma",
+                "kernel": "gemm_kernel<float,false,false,1> (V = W K*^T with fused column-norm epilogue, 1 launch/step)"
+                          if args.var_method == "inverse" else
+                          "gemm_kernel<float,false,true,0> (all launches of the triangular solve)",
+                "achieved": flops / k5_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": flops / k5_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                "launches_per_step": n_launch, "k5_ms": k5_s * 1e3,
                 "algorithmic_flops_per_step": flops}
-        del work
+        del work, var
 
     if rank == 0:
         total_pred = float(M) * world * args.steps

@@ -126,6 +126,23 @@ int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, co
                     const void* Xq, int64_t M, double kss, double floor, void* work,
                     double* var);
 
+/* ---- K5, serving form: variance through the explicit inverse factor ---------------------------------
+ * gpk_trtri: W (dev Np x ldw, fp64) <- L^-1, lower triangle by tiles (recursive, fp64-MFMA GEMMs);
+ * one-off N^3/3 flops after the factorisation.  work: dev double[(Np/2 + 128)^2].
+ * gpk_tril_to_f32: fp32 copy of the lower triangle (tiles on/below the diagonal).
+ * gpk_predict_var_inv: var[m] = max(kss - |W k*_m|^2, floor) in ONE GEMM launch: the tile of
+ * V = W K*^T is reduced to column sums of squares in the epilogue and never written to HBM; W's
+ * zero upper triangle is skipped (N^2 M flops).  W, X, Xq of `dtype`; work: dev scratch of
+ * Mp * Np elements of `dtype`; var: dev double[Mp].
+ * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485),
+ * with solve_triangular(L, K*^T) evaluated as (L^-1) K*^T.                                          */
+int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
+              int64_t ldw, double* work);
+int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_t lda, float* Af, int64_t ldaf);
+int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+                        double sf2, const void* W, int64_t Np, int64_t ldw, const void* Xq, int64_t M,
+                        double kss, double floor, void* work, double* var);
+
 /* ---- K6a: log-marginal-likelihood terms -----------------------------------------------------
  * terms[0] = sum_{i<N} log L[i][i]; terms[1 + p] = sum_i Y[i][p] * alpha[i][p]  (host doubles).
  * Synchronises.  Replaces: sklearn/gaussian_process/_gpr.py:609-613; gaussian_process.py:250-261. */

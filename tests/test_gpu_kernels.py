@@ -60,6 +60,28 @@ def test_gemm_tiles_random_and_lower(be):
     be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(Ad), k, _p(Ad), k, _p(Cd), m, m, m, k, -1.0, 1.0, 1))
     out = Cd.cpu().numpy()
     ref = C0 - A @ A.T
+    # > 512 tiles: exercises the super-tile mapping, full and lower-triangular
+    m2, k2 = 3200, 128
+    A2 = rng.standard_normal((m2, k2))
+    A2d = be.upload(A2)
+    for lower in (0, 1):
+        C2d = be.upload(np.zeros((m2, m2)))
+        be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(A2d), k2, _p(A2d), k2, _p(C2d), m2, m2, m2, k2, 1.0,
+                                       0.0, lower))
+        o2 = C2d.cpu().numpy()
+        r2 = A2 @ A2.T
+        if lower:
+            msk = np.kron(np.tril(np.ones((25, 25))), np.ones((128, 128))).astype(bool)
+            assert relerr(o2[msk], r2[msk]) < 1e-13 and not o2[~msk].any()
+        else:
+            assert relerr(o2, r2) < 1e-13
+    # short-and-wide / tall-and-narrow grids (adaptive super-tile shape)
+    for (mm, nn) in ((256, 40 * 128), (40 * 128, 384)):
+        Aa, Bb = rng.standard_normal((mm, 64)), rng.standard_normal((nn, 64))
+        Ad2, Bd2, Cd2 = be.upload(Aa), be.upload(Bb), be.upload(np.zeros((mm, nn)))
+        be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(Ad2), 64, _p(Bd2), 64, _p(Cd2), nn, mm, nn, 64, 1.0,
+                                       0.0, 0))
+        assert relerr(Cd2.cpu().numpy(), Aa @ Bb.T) < 1e-13
     tiles_lower = np.kron(np.tril(np.ones((m // 128, m // 128))), np.ones((128, 128))).astype(bool)
     assert relerr(out[tiles_lower], ref[tiles_lower]) < 1e-13
     assert np.array_equal(out[~tiles_lower], C0[~tiles_lower])      # skipped tiles untouched
@@ -169,10 +191,15 @@ def test_trsm_colsumsq_fp64_fp32(be):
     Ks = O.rbf_cross(Xq, X, 2.0, 1.0)
     V = solve_triangular(st.L, Ks.T, lower=True)
     ref = np.einsum("ij,ij->j", V, V)
-    v64 = dev.predict_var_dev(Xq, 1.1, 0.0, "float64").cpu().numpy()
-    assert relerr(1.1 - v64, ref) < 1e-11
-    v32 = dev.predict_var_dev(Xq, 1.1, 0.0, "float32").cpu().numpy()
-    assert np.max(np.abs(v32 - np.maximum(1.1 - ref, 0))) < 5e-5
+    for method in ("solve", "inverse"):
+        v64 = dev.predict_var_dev(Xq, 1.1, 0.0, "float64", method).cpu().numpy()
+        assert relerr(1.1 - v64, ref) < 1e-11, method
+        v32 = dev.predict_var_dev(Xq, 1.1, 0.0, "float32", method).cpu().numpy()
+        assert np.max(np.abs(v32 - np.maximum(1.1 - ref, 0))) < 5e-5, method
+    # the explicit inverse itself: W L = I on the lower tiles
+    W = np.tril(dev.inverse_factor(False).cpu().numpy())
+    Lp = np.tril(dev.K.cpu().numpy())
+    assert np.max(np.abs(W @ Lp - np.eye(dev.Np))) < 1e-11
 
 
 def test_predict_mean_fp64_fp32(be, csv_data, ka):

@@ -39,6 +39,10 @@ SIGNATURES = {
     "gpk_predict_mean": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,
                                _dbl, _vp, _vp]),
+    "gpk_trtri": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "gpk_tril_to_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
+    "gpk_predict_var_inv": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _i64, _dbl, _dbl,
+                                   _vp, _vp]),
     "gpk_lml_terms": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int, _dp]),
     "gpk_potri": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "gpk_lml_grad": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _int, _vp, _i64, _dp]),

@@ -86,6 +86,30 @@ extern "C" int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N
   return gpk_var_finalize(h, var, M, kss, floor_, var);
 }
 
+extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+                                   double sf2, const void* W, int64_t Np, int64_t ldw, const void* Xq, int64_t M,
+                                   double kss, double floor_, void* work, double* var) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && W && Xq && work && var, "predict_var_inv: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && Np == gpk_padded(N) && ldw >= Np, "predict_var_inv: Np must equal gpk_padded(N)");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "predict_var_inv: bad dtype");
+  const int64_t Mp = gpk_padded(M);
+  // Kq (Mp x Np, query-major, k contiguous) = k(Xq, X); zero in the padding
+  GPK_TRY(gpk_cross_gram_t(h, dtype, Xq, M, X, N, D, ls, sf2, work, Np));
+  // one launch: V = W Kq^T tile by tile (W lower: k < row-tile end), V never stored, only the per-tile
+  // column sums of squares: partial[tile_row][m]
+  const int ntm = (int)(Np / GPK_TILE);
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
+  GemmArgs g = gemm_args(W, ldw, 0, work, Np, 0, partial, Mp, (int)Np, (int)Mp, (int)Np, 1.0, 0.0);
+  g.ke0 = GPK_TILE;
+  g.ke_row = GPK_TILE;
+  g.epilogue = 1;
+  GPK_TRY(gpk_gemm(h, dtype, g));
+  GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
+  return gpk_var_finalize(h, var, M, kss, floor_, var);
+}
+
 extern "C" int gpk_gemm_tiles(gpk_handle h, int dtype, int ta, int tb, const void* A, int64_t lda, const void* B,
                               int64_t ldb, void* C, int64_t ldc, int64_t m, int64_t n, int64_t k, double alpha,
                               double beta, int lower_only) {

@@ -12,73 +12,143 @@
 namespace {
 
 constexpr int NB = 128;       // leaf size
-constexpr int LS = NB + 1;    // LDS row stride (doubles)
 
-// ---- leaf: unblocked right-looking Cholesky of one 128 x 128 block in LDS ---------------------
-// Columns stay unscaled during the sweep (u_ij = a_ij - sum_t l_it l_jt); the rank-1 update of
-// step j uses u_ij u_kj / u_jj, and a final pass divides column j by sqrt(u_jj).  One barrier
-// per column.
-__global__ __launch_bounds__(256) void potf2_leaf_kernel(double* __restrict__ A, long long lda, int row0,
-                                                         int* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double a[NB * LS];
-  __shared__ double piv[NB];
-  const int tid = threadIdx.x;
+// ---- leaf: Cholesky factor AND inverse of one 128 x 128 diagonal block, one workgroup ------------
+// The block lives in LDS (row stride 130 doubles: conflict-free ds_read_b64 for the MFMA operand
+// pattern row = lane & 15, k = lane >> 4).  Blocked left-looking sweep with 16 x 16 sub-blocks:
+//   P1  block column jb  -= L[ib, 0:jb] L[jb, 0:jb]^T          fp64 MFMA 16x16x4, one block per wave
+//   P2  16 x 16 diagonal block: unblocked right-looking factorisation (256 threads, one per element)
+//   P3  rows below: x L_jj^T = a by substitution, one thread per row; 16 extra threads solve the
+//       identity rows, which yields W_jj^T = L_jj^-T for the inverse
+// then the inverse W = L^-1 block diagonal by block diagonal on the MFMA:
+//   W_ij = -W_ii (sum_{k=j}^{i-1} L_ik W_kj),   i - j = 1 .. 7
+// The inner sum's accumulator is used directly as the B operand of the second product (the f64
+// C/D map row = (lane >> 4) + 4 reg is exactly the B-operand map of k-step reg).  Off-diagonal W
+// blocks are parked transposed in the (otherwise unused) upper triangle of the LDS image.
+// FACTOR == false: the block already holds a factor (imported model); only W is produced.
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int LSA = 130;   // LDS row stride of the 128 x 128 image
+constexpr int LSW = 18;    // row stride of the 16 x 16 diagonal inverses
+
+template <bool FACTOR>
+__global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, long long lda, int row0,
+                                                   int* __restrict__ info, double* __restrict__ W) {
+  __shared__ __attribute__((aligned(16))) double a[NB * LSA];
+  __shared__ __attribute__((aligned(16))) double wd[8 * 16 * LSW];   // wd[b][r][c] = W_bb[c][r]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e >> 7, j = e & 127;
-    a[i * LS + j] = (j <= i) ? A[(long long)i * lda + j] : 0.0;
+    a[i * LSA + j] = (j <= i) ? A[(long long)i * lda + j] : 0.0;
   }
   __syncthreads();
-  const int ro = tid >> 1, half = tid & 1;
-  for (int j = 0; j < NB; ++j) {
-    double ajj = a[j * LS + j];
-    if (!(ajj > 0.0)) {                     // not positive definite (or NaN): record, keep going finite
-      if (tid == 0) atomicCAS(info, 0, row0 + j + 1);
-      ajj = 1.0;
-    }
-    if (tid == 0) piv[j] = ajj;
-    const double rinv = 1.0 / ajj;
-    const int i = j + 1 + ro;
-    if (i < NB) {
-      const double s = a[i * LS + j] * rinv;
-      for (int k = j + 1 + half; k <= i; k += 2) a[i * LS + k] = __builtin_fma(-s, a[k * LS + j], a[i * LS + k]);
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    if (j <= i) {
-      const double d = __builtin_sqrt(piv[j]);
-      A[(long long)i * lda + j] = (j == i) ? d : a[i * LS + j] / d;
-    }
-  }
-}
 
-// ---- leaf: W = L^-1 of one 128 x 128 lower-triangular block -----------------------------------
-// Column c of W by forward substitution; two threads (different waves) split each dot product,
-// so the (i, k) sweep is wave-uniform and L is read through the scalar path.
-__global__ __launch_bounds__(256) void trtri_leaf_kernel(const double* __restrict__ L, long long ldl,
-                                                         double* __restrict__ W) {
-  __shared__ __attribute__((aligned(16))) double x[NB * LS];   // x[k][c]
-  __shared__ double part[NB];
-  const int tid = threadIdx.x;
-  const int c = tid & 127, half = tid >> 7;
-  for (int i = 0; i < NB; ++i) {
-    const int mid = i >> 1;
-    const int k0 = half ? mid : 0, k1 = half ? i : mid;
-    double s = 0.0;
-    for (int k = k0; k < k1; ++k) s = __builtin_fma(L[(long long)i * ldl + k], x[k * LS + c], s);
-    if (half) part[c] = s;
-    __syncthreads();
-    if (!half) {
-      s += part[c];
-      const double rhs = (i == c) ? 1.0 : 0.0;
-      x[i * LS + c] = (c <= i) ? (rhs - s) / L[(long long)i * ldl + i] : 0.0;
+  for (int jb = 0; jb < 8; ++jb) {
+    const int c0 = 16 * jb;
+    if (FACTOR) {
+      // ---- P1: left-looking update of block column jb
+      if (jb > 0) {
+        for (int ib = jb + wave; ib < 8; ib += 4) {
+          d4 acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = a[(16 * ib + lq + 4 * r) * LSA + c0 + lr];
+          for (int kb = 0; kb < jb; ++kb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const double av = a[(16 * ib + lr) * LSA + 16 * kb + 4 * s + lq];
+              const double bv = -a[(c0 + lr) * LSA + 16 * kb + 4 * s + lq];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[(16 * ib + lq + 4 * r) * LSA + c0 + lr] = acc[r];
+        }
+        __syncthreads();
+      }
+      // ---- P2: unblocked factorisation of the 16 x 16 diagonal block (columns stay unscaled)
+      {
+        const int i = tid >> 4, k = tid & 15;
+        for (int c = 0; c < 16; ++c) {
+          double d = a[(c0 + c) * LSA + c0 + c];
+          if (!(d > 0.0)) {                      // not positive definite (or NaN): record, stay finite
+            if (tid == 0) atomicCAS(info, 0, row0 + c0 + c + 1);
+            d = 1.0;
+          }
+          if (i > c && k > c && k <= i)
+            a[(c0 + i) * LSA + c0 + k] -= a[(c0 + i) * LSA + c0 + c] * a[(c0 + k) * LSA + c0 + c] / d;
+          __syncthreads();
+        }
+        double p = a[(c0 + k) * LSA + c0 + k];
+        if (!(p > 0.0)) p = 1.0;
+        const double v = a[(c0 + i) * LSA + c0 + k];
+        __syncthreads();
+        if (k <= i) {
+          const double sq = __builtin_sqrt(p);
+          a[(c0 + i) * LSA + c0 + k] = (i == k) ? sq : v / sq;
+        }
+        __syncthreads();
+      }
+    }
+    // ---- P3: panel rows x L_jj^T = a (threads 0..111) and identity rows -> W_jj^T (threads 112..127)
+    if (tid < 128) {
+      const bool ident = tid >= 112;
+      const int row = ident ? (tid - 112) : (c0 + 16 + tid);
+      if (ident || (FACTOR && row < NB)) {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = ident ? ((c == row) ? 1.0 : 0.0) : a[row * LSA + c0 + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          x[c] = x[c] / a[(c0 + c) * LSA + c0 + c];
+#pragma unroll
+          for (int c2 = c + 1; c2 < 16; ++c2) x[c2] = __builtin_fma(-x[c], a[(c0 + c2) * LSA + c0 + c], x[c2]);
+        }
+        if (ident) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) wd[(jb * 16 + row) * LSW + c] = x[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) a[row * LSA + c0 + c] = x[c];
+        }
+      }
     }
     __syncthreads();
   }
+
+  // ---- inverse, block diagonal by block diagonal
+  for (int d = 1; d < 8; ++d) {
+    for (int i = d + wave; i < 8; i += 4) {
+      const int j = i - d;
+      d4 S = {0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; ++k) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double av = a[(16 * i + lr) * LSA + 16 * k + 4 * s + lq];                 // L_ik[r][k']
+          const double bv = (k == j) ? wd[(j * 16 + lr) * LSW + 4 * s + lq]               // W_jj[k'][c]
+                                     : a[(16 * j + lr) * LSA + 16 * k + 4 * s + lq];       // W_kj[k'][c]
+          S = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, S, 0, 0, 0);
+        }
+      }
+      d4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double av = wd[(i * 16 + 4 * s + lq) * LSW + lr];                           // W_ii[r][k']
+        R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, S[s], R, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[(16 * j + lr) * LSA + 16 * i + lq + 4 * r] = -R[r];    // W_ij^T
+    }
+    __syncthreads();
+  }
+
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e >> 7, j = e & 127;
-    W[i * NB + j] = x[i * LS + j];
+    if (FACTOR && j <= i) A[(long long)i * lda + j] = a[i * LSA + j];
+    const int bi = i >> 4, bj = j >> 4;
+    double w = 0.0;
+    if (bi > bj) w = a[(16 * bj + (j & 15)) * LSA + 16 * bi + (i & 15)];
+    else if (bi == bj) w = wd[(bi * 16 + (j & 15)) * LSW + (i & 15)];
+    W[i * NB + j] = w;
   }
 }
 
@@ -160,11 +230,8 @@ int trsm_right_rec(gpk_handle h, double* B, int64_t ldb, int64_t m, const double
 
 int potrf_rec(gpk_handle h, double* A, int64_t lda, int64_t n, double* winv, int64_t row0) {
   if (n == NB) {
-    hipLaunchKernelGGL(potf2_leaf_kernel, dim3(1), dim3(256), 0, h->stream, A,
-                       (long long)lda, (int)row0, h->d_info);
-    GPK_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(256), 0, h->stream,
-                       (const double*)A, (long long)lda, winv);
+    hipLaunchKernelGGL(leaf_kernel<true>, dim3(1), dim3(256), 0, h->stream, A, (long long)lda, (int)row0, h->d_info,
+                       winv);
     GPK_LAUNCH_CHECK(h);
     return GPK_OK;
   }
@@ -257,8 +324,9 @@ extern "C" int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int6
   GPK_REQUIRE(h, L && winv, "leaf_inverses: null pointer");
   GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && ldl >= Np, "leaf_inverses: Np must be a positive multiple of 128");
   for (int64_t b = 0; b < Np / NB; ++b) {
-    hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(256), 0, h->stream, L + b * NB * ldl + b * NB,
-                       (long long)ldl, winv + b * NB * NB);
+    hipLaunchKernelGGL(leaf_kernel<false>, dim3(1), dim3(256), 0, h->stream,
+                       const_cast<double*>(L) + b * NB * ldl + b * NB, (long long)ldl, 0, h->d_info,
+                       winv + b * NB * NB);
     GPK_LAUNCH_CHECK(h);
   }
   return GPK_OK;
@@ -321,6 +389,25 @@ extern "C" int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t l
   GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, (1 + P) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < 1 + P; ++i) terms[i] = h->h_small[i];
+  return GPK_OK;
+}
+
+extern "C" int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
+                         int64_t ldw, double* work) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, L && winv && W && work, "trtri: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldl >= Np && ldw >= Np, "trtri: Np must be a multiple of 128");
+  const int64_t n1 = half_split(Np);
+  return trtri_rec(h, L, ldl, Np, winv, W, ldw, work, n1 > 0 ? n1 : NB);
+}
+
+extern "C" int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_t lda, float* Af, int64_t ldaf) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, A && Af, "tril_to_f32: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && lda >= Np && ldaf >= Np, "tril_to_f32: bad size");
+  hipLaunchKernelGGL(tril_to_f32_kernel, dim3((unsigned)Np, (unsigned)((Np + 255) / 256)), dim3(256), 0, h->stream, A,
+                     (long long)Np, (long long)lda, Af, (long long)ldaf);
+  GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }
 

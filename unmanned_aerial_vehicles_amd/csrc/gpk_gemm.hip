@@ -38,8 +38,9 @@ struct KParams {
   long long lda, ldb, ldc;  // in elements
   int m, n, k;
   double alpha, beta;
-  int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col, heavy_first;
+  int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;
   int ntm, ntn;
+  int direct, nst, nsc, sr;   // tile mapping: direct grid, or super-tiles (count, per super-row, rows)
 };
 
 typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
@@ -224,25 +225,79 @@ template <typename T> struct AccT;
 template <> struct AccT<double> { typedef d4 type[4][4]; };
 template <> struct AccT<float> { typedef f16v type[2][2]; };
 
-template <typename T, bool TA, bool TB>
+// Epilogue 1 (column sums of squares): instead of storing the 128 x 128 tile, store for each of its
+// 128 columns the sum over the tile's rows of (alpha * acc)^2, in fp64, at C[tile_row * ldc + col].
+__device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, long long ldo, int tm, int col0,
+                                          int wm, int wn, int lane, int tid, const d4 (&acc)[4][4], double alpha) {
+  double* red = reinterpret_cast<double*>(lds);   // [2][128]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double v = alpha * acc[a][b][i]; s = __builtin_fma(v, v, s); }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[wm * 128 + wn * 64 + 16 * b + lane] = s;
+  }
+  __syncthreads();
+  if (tid < 128) out[(long long)tm * ldo + col0 + tid] = red[tid] + red[128 + tid];
+}
+__device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, long long ldo, int tm, int col0,
+                                          int wm, int wn, int lane, int tid, const f16v (&acc)[2][2], double alpha) {
+  double* red = reinterpret_cast<double*>(lds);
+  const float al = (float)alpha;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float v = al * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 32) red[wm * 128 + wn * 64 + 32 * b + lane] = (double)s;
+  }
+  __syncthreads();
+  if (tid < 128) out[(long long)tm * ldo + col0 + tid] = red[tid] + red[128 + tid];
+}
+
+template <typename T, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
   __shared__ __attribute__((aligned(16))) char lds[4 * LDS_OP_BYTES];
   constexpr int BK = Cfg<T>::BK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- XCD-aware tile mapping: each XCD sweeps a contiguous range of a grouped order ----
-  const int nb = gridDim.x, pid = blockIdx.x;
-  const int xcd = pid & 7, q = nb >> 3, rem = nb & 7;
-  const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (pid >> 3);
-  constexpr int GROUP_M = 8;
-  const int in_group = GROUP_M * p.ntn;
-  const int group = id / in_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(p.ntm - first_m, GROUP_M);
-  int tm = first_m + (id % in_group) % gsize;
-  const int tn = (id % in_group) / gsize;
-  if (p.heavy_first) tm = p.ntm - 1 - tm;
+  // ---- tile mapping.  Grids that fit one residency round (<= 512 tiles) map block -> tile directly.
+  // Larger grids are cut into super-tiles of 64 tiles (8 x 8, or sr x 64/sr for short grids); hardware
+  // workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x takes super-tiles x, x+8, x+16, ...
+  // and walks the 64 tiles of one super-tile with its 64 resident workgroups (32 CUs x 2): the 8 + 8
+  // operand panels of a super-tile are shared through that XCD's L2, and every XCD sees an even
+  // sample of the tile grid (triangular problems stay balanced).  lower_only enumerates only the
+  // super-tiles on or below the diagonal.
+  int tm, tn;
+  if (p.direct) {
+    tm = blockIdx.x % p.ntm;
+    tn = blockIdx.x / p.ntm;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int st = (j >> 6) * 8 + xcd, slot = j & 63;
+    if (st >= p.nst) return;
+    int R, S;
+    if (p.lower_only) {
+      R = (int)((__builtin_sqrtf(8.0f * (float)st + 1.0f) - 1.0f) * 0.5f);
+      while ((R + 1) * (R + 2) / 2 <= st) ++R;
+      while (R * (R + 1) / 2 > st) --R;
+      S = st - R * (R + 1) / 2;
+    } else {
+      R = st / p.nsc;
+      S = st - R * p.nsc;
+    }
+    tm = p.sr * R + (slot & (p.sr - 1));
+    tn = (64 / p.sr) * S + slot / p.sr;
+    if (tm >= p.ntm || tn >= p.ntn) return;
+  }
   if (p.lower_only && tn > tm) return;
 
   int kb = p.kb0 + p.kb_row * tm + p.kb_col * tn;
@@ -287,7 +342,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
       __syncthreads();
     }
   }
-  store_acc(C, p.ldc, row0, col0, wm, wn, lane, acc, p.alpha, p.beta);
+  if constexpr (EPI == 0) {
+    store_acc(C, p.ldc, row0, col0, wm, wn, lane, acc, p.alpha, p.beta);
+  } else {
+    // the k-loop ended with a barrier: the staging buffers are free for the reduction
+    sumsq_acc(lds, reinterpret_cast<double*>(p.C), p.ldc, tm, col0, wm, wn, lane, tid, acc, p.alpha);
+  }
 }
 
 template <typename T>
@@ -299,13 +359,32 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.alpha = g.alpha; p.beta = g.beta;
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
   p.ke0 = g.ke0; p.ke_row = g.ke_row; p.ke_col = g.ke_col;
-  p.heavy_first = g.heavy_first;
   p.ntm = g.m / BM; p.ntn = g.n / BN;
-  dim3 grid(p.ntm * p.ntn), block(256);
-  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, h->stream, p);
-  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, h->stream, p);
-  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, h->stream, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, h->stream, p);
+  const long long ntiles = g.lower_only ? (long long)p.ntm * (p.ntm + 1) / 2 : (long long)p.ntm * p.ntn;
+  p.direct = ntiles <= 512 ? 1 : 0;
+  p.sr = 8;
+  if (!g.lower_only) {
+    while (p.sr > p.ntm) p.sr >>= 1;                 // short grids: sr x (64 / sr) super-tiles
+    if (p.ntn < 8) { p.sr = 8; while (64 / p.sr > p.ntn && p.sr < 64) p.sr <<= 1; }
+  }
+  const int sc = 64 / p.sr;
+  const int nsr = (p.ntm + p.sr - 1) / p.sr;
+  p.nsc = (p.ntn + sc - 1) / sc;
+  p.nst = g.lower_only ? nsr * (nsr + 1) / 2 : nsr * p.nsc;
+  const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
+  if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
+  dim3 grid((unsigned)nblocks), block(256);
+  if (g.epilogue == 1) {
+    if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }
+    if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, false, true, 1>), grid, block, 0, h->stream, p);
+    GPK_LAUNCH_CHECK(h);
+    return GPK_OK;
+  }
+  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 0>), grid, block, 0, h->stream, p);
+  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, 0>), grid, block, 0, h->stream, p);
+  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, 0>), grid, block, 0, h->stream, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true, 0>), grid, block, 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }

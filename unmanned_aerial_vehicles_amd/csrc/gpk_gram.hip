@@ -472,6 +472,13 @@ extern "C" int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, 
   return GPK_OK;
 }
 
+int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out) {
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, h->stream, partial, S,
+                     (long long)Mp, out);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var) {
   hipLaunchKernelGGL(var_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, ss,
                      (long long)M, kss, floor_, var);

@@ -124,6 +124,7 @@ class DeviceGP:
         self.ls = None
         self.sf2 = None
         self._f32 = None    # dict of fp32 copies: X, alpha [, L, winv]
+        self._Winv = {}     # explicit inverse factor L^-1: {'f64': tensor} and/or {'f32': tensor}
         self._Kinv = None
         self._W = None
 
@@ -146,6 +147,7 @@ class DeviceGP:
         self.ls, self.sf2 = ls, float(sf2)
         self.factored = False
         self._f32 = None
+        self._Winv = {}
 
     def factorize(self, ls, sf2, diag_add):
         """K1 + K2: Gram build and in-place blocked Cholesky.  Raises NotPositiveDefinite."""
@@ -172,6 +174,7 @@ class DeviceGP:
         self.sf2 = float(sf2)
         self.factored = True
         self._f32 = None
+        self._Winv = {}
 
     def solve_alpha(self):
         """K3: alpha = L^-T L^-1 Yn."""
@@ -288,36 +291,80 @@ class DeviceGP:
                                              _p(out)))
         return out
 
-    def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64"):
-        """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units)."""
+    def inverse_factor(self, f32):
+        """W = L^-1 (lower, by tiles) on the fp64 MFMA; kept as fp64 or as an fp32 copy.  One-off
+        N^3/3 flops per factorisation; makes every later variance call a single GEMM launch."""
+        torch = _torch()
+        assert self.factored
+        key = "f32" if f32 else "f64"
+        if key not in self._Winv:
+            be = self.be
+            W = self._Winv.get("f64")
+            if W is None:
+                W = be.empty((self.Np, self.Np), torch.float64)
+                work = be.empty(((self.Np // 2 + 128) ** 2,), torch.float64)
+                with be.lock:
+                    be.bind_stream()
+                    be.check(be.lib.gpk_trtri(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(W), self.Np,
+                                              _p(work)))
+                del work
+            if f32:
+                Wf = be.empty((self.Np, self.Np), torch.float32)
+                with be.lock:
+                    be.bind_stream()
+                    be.check(be.lib.gpk_tril_to_f32(be.h, _p(W), self.Np, self.Np, _p(Wf), self.Np))
+                self._Winv["f32"] = Wf
+            else:
+                self._Winv["f64"] = W
+        return self._Winv[key]
+
+    def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64", method="auto"):
+        """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units).
+
+        method "solve": V = L^-1 K*^T by the blocked triangular solve (the reference's
+        solve_triangular), "inverse": |W k*|^2 with the explicit inverse factor in one fused GEMM
+        launch, "auto": inverse for fp32 (serving), solve for fp64."""
         torch = _torch()
         assert self.factored
         f32 = dtype in ("float32", np.float32, torch.float32)
+        if method == "auto":
+            method = "inverse" if f32 else "solve"
+        if method not in ("solve", "inverse"):
+            raise ValueError("method must be 'auto', 'solve' or 'inverse'")
         tdt = torch.float32 if f32 else torch.float64
         es = 4 if f32 else 8
+        code = GPK_F32 if f32 else GPK_F64
         q = self._as_queries(Xq, tdt)
         M = q.shape[0]
         out = self.be.empty((M,), torch.float64)
         if M == 0:
             return out
-        if f32:
+        Xd = self._f32_data()["X"] if f32 else self.X
+        if method == "inverse":
+            Wd = self.inverse_factor(f32)
+        elif f32:
             c = self._f32_factor()
-            Xd, Ld, wd = c["X"], c["L"], c["winv"]
+            Ld, wd = c["L"], c["winv"]
         else:
-            Xd, Ld, wd = self.X, self.K, self.winv
+            Ld, wd = self.K, self.winv
         panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * es)) // 128 * 128))
         panel = min(panel, padded(M))
         work = self.be.empty((self.Np * panel,), tdt)
         var = self.be.empty((panel,), torch.float64)
         be = self.be
+        lsp = self.ls.ctypes.data_as(_lib._dp)
         with be.lock:
             be.bind_stream()
             for m0 in range(0, M, panel):
                 m1 = min(M, m0 + panel)
-                be.check(be.lib.gpk_predict_var(be.h, GPK_F32 if f32 else GPK_F64, _p(Xd), self.N, self.D,
-                                                self.ls.ctypes.data_as(_lib._dp), self.sf2, _p(Ld), self.Np,
-                                                self.Np, _p(wd), _p(q[m0:m1]), m1 - m0, float(kss), float(floor),
-                                                _p(work), _p(var)))
+                if method == "inverse":
+                    be.check(be.lib.gpk_predict_var_inv(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Wd),
+                                                        self.Np, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
+                                                        float(floor), _p(work), _p(var)))
+                else:
+                    be.check(be.lib.gpk_predict_var(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Ld),
+                                                    self.Np, self.Np, _p(wd), _p(q[m0:m1]), m1 - m0, float(kss),
+                                                    float(floor), _p(work), _p(var)))
                 out[m0:m1].copy_(var[: m1 - m0])
         return out
 
