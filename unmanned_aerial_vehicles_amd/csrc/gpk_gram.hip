@@ -6,6 +6,8 @@
 //       colsumsq kernels   column sums of squares of V = L^-1 K*^T (fp64 accumulation)
 // Squared distances are formed from exact differences of inputs pre-divided by the
 // length-scale (the cdist/pdist form of the reference), never by the norm expansion.
+#include <cstdlib>
+
 #include "gpk_internal.h"
 
 namespace {
@@ -63,15 +65,24 @@ __device__ __forceinline__ void st16(float* p, float a, float b, float c, float 
   if (nt) __builtin_nontemporal_store(v, reinterpret_cast<fv4*>(p));
   else *reinterpret_cast<fv4*>(p) = v;
 }
-__device__ __forceinline__ void store_row4(double* p, const double (&v)[4], bool nt) {
-  st16(p, v[0], v[1], nt);
-  st16(p + 2, v[2], v[3], nt);
+// p = start of the 64-column tile row; writes thread tx's four columns (see colof)
+__device__ __forceinline__ void store_row4(double* p, int tx, const double (&v)[4], bool nt) {
+  st16(p + 2 * tx, v[0], v[1], nt);
+  st16(p + 32 + 2 * tx, v[2], v[3], nt);
 }
-__device__ __forceinline__ void store_row4(float* p, const float (&v)[4], bool nt) {
-  st16(p, v[0], v[1], v[2], v[3], nt);
+__device__ __forceinline__ void store_row4(float* p, int tx, const float (&v)[4], bool nt) {
+  st16(p + 4 * tx, v[0], v[1], v[2], v[3], nt);
 }
 
 constexpr int TS = 64;    // tile edge
+
+// Column c (0..3) of thread tx's 4 x 4 micro-tile.  fp32: 4 consecutive columns (one 16-byte store);
+// fp64: two pairs, {2tx, 2tx+1} and {32+2tx, 32+2tx+1}, so that each 16-byte store instruction of
+// 16 neighbouring lanes covers 256 contiguous bytes (whole 128-byte lines) instead of every other
+// 16-byte piece.
+template <typename T> __device__ __forceinline__ int colof(int tx, int c);
+template <> __device__ __forceinline__ int colof<double>(int tx, int c) { return (c >> 1) * 32 + 2 * tx + (c & 1); }
+template <> __device__ __forceinline__ int colof<float>(int tx, int c) { return 4 * tx + c; }
 constexpr int DCH = 16;   // feature chunk held in LDS
 
 // Stage rows [r0, r0+64) of X (n x D) scaled by 1/ls into lds[d][64] for d in [d0, d0+dc).
@@ -95,7 +106,7 @@ __device__ __forceinline__ void accum_d2(const T* xi, const T* xj, int dc, int t
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = xi[d * TS + 4 * ty + r];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = xj[d * TS + 4 * tx + c];
+    for (int c = 0; c < 4; ++c) b[c] = xj[d * TS + colof<T>(tx, c)];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -144,13 +155,13 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ X, 
     const long long gi = i0 + 4 * ty + r;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const long long gj = j0 + 4 * tx + c;
+      const long long gj = j0 + colof<T>(tx, c);
       T val = sf2 * exp_neg(T(-0.5) * d2[r][c]);
       if (gi == gj) val = sf2 + diag_add;            // RBF diagonal is exactly sf2 (+ white + jitter)
       if (gi >= N || gj >= N) val = (gi == gj) ? T(1) : T(0);   // identity padding
       v[r][c] = val;
     }
-    store_row4(K + gi * ldk + j0 + 4 * tx, v[r], NT);
+    store_row4(K + gi * ldk + j0, tx, v[r], NT);
   }
   if (ti == tj) return;
 
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ X, 
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) tb[(4 * ty + r) * (TS + 1) + 4 * tx + c] = v[r][c];
+    for (int c = 0; c < 4; ++c) tb[(4 * ty + r) * (TS + 1) + colof<T>(tx, c)] = v[r][c];
   __syncthreads();
   constexpr int VEC = Vec16<T>::N;      // elements per 16-byte store
   constexpr int LPR = TS / VEC;         // lanes per output row
@@ -204,12 +215,12 @@ __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, l
     T v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const long long gj = j0 + 4 * tx + c;
+      const long long gj = j0 + colof<T>(tx, c);
       T val = sf2 * exp_neg(T(-0.5) * d2[r][c]);
       if (gi >= N || gj >= M) val = T(0);
       v[c] = val;
     }
-    store_row4(B + gi * ldb + j0 + 4 * tx, v, false);
+    store_row4(B + gi * ldb + j0, tx, v, false);
   }
 }
 
@@ -360,7 +371,8 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
   const int64_t nt = Np / TS;
   const int64_t tiles = nt * (nt + 1) / 2;
   GPK_REQUIRE(h, tiles < (1ll << 31), "gram: N too large");
-  const bool stream_nt = Np >= 16384;   // streaming stores once K exceeds the caches
+  bool stream_nt = Np >= 16384;   // streaming stores once K exceeds the caches
+  if (const char* e = getenv("GPK_GRAM_NT")) stream_nt = (e[0] == '1');   // tuning override
   GPK_REQUIRE(h, ((uintptr_t)K % 16) == 0, "gram: K must be 16-byte aligned");
   const dim3 grid((unsigned)tiles), block(256);
 #define GPK_GRAM_LAUNCH(T, NT)                                                                          \
