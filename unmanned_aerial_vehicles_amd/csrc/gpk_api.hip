@@ -105,6 +105,7 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   g.ke0 = GPK_TILE;
   g.ke_row = GPK_TILE;
   g.epilogue = 1;
+  g.heavy_first = 1;   // row tile tm costs (tm + 1) k-blocks: start the long ones first
   GPK_TRY(gpk_gemm(h, dtype, g));
   GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
   return gpk_var_finalize(h, var, M, kss, floor_, var);

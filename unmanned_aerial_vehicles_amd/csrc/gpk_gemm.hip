@@ -40,6 +40,7 @@ struct KParams {
   double alpha, beta;
   int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;
   int ntm, ntn;
+  int heavy_first;            // reverse the tile-row order (k-range grows with the row: longest tiles first)
   int direct, nst, nsc, sr;   // tile mapping: direct grid, or super-tiles (count, per super-row, rows)
 };
 
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
     tn = (64 / p.sr) * S + slot / p.sr;
     if (tm >= p.ntm || tn >= p.ntn) return;
   }
+  if (p.heavy_first) tm = p.ntm - 1 - tm;
   if (p.lower_only && tn > tm) return;
 
   int kb = p.kb0 + p.kb_row * tm + p.kb_col * tn;
@@ -359,6 +361,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.alpha = g.alpha; p.beta = g.beta;
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
   p.ke0 = g.ke0; p.ke_row = g.ke_row; p.ke_col = g.ke_col;
+  p.heavy_first = g.heavy_first;
   p.ntm = g.m / BM; p.ntn = g.n / BN;
   const long long ntiles = g.lower_only ? (long long)p.ntm * (p.ntm + 1) / 2 : (long long)p.ntm * p.ntn;
   p.direct = ntiles <= 512 ? 1 : 0;

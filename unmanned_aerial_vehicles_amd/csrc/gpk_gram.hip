@@ -49,6 +49,11 @@ __device__ __forceinline__ float exp_neg(float x) {
   return __builtin_fmaf(e, lo * 0.693147180559945f, e);
 }
 
+// type-exact fused multiply-add (the bare __builtin_fma is the double version: on floats it would
+// round-trip through fp64)
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 template <typename T> struct Vec16;
 template <> struct Vec16<double> { typedef double2 type; static constexpr int N = 2; };
 template <> struct Vec16<float> { typedef float4 type; static constexpr int N = 4; };
@@ -112,7 +117,7 @@ __device__ __forceinline__ void accum_d2(const T* xi, const T* xj, int dc, int t
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const T df = a[r] - b[c];
-        d2[r][c] = __builtin_fma(df, df, d2[r][c]);
+        d2[r][c] = fma_t(df, df, d2[r][c]);
       }
   }
 }
@@ -225,71 +230,82 @@ __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, l
 }
 
 // ---- K4: fused posterior mean ---------------------------------------------------------------------
-// One thread owns QPT queries (coordinates and P accumulators in registers); training rows
-// [x_j / ls | alpha_j] are staged through LDS and read as wave-uniform broadcasts.  The training
-// set is split over gridDim.y; partial sums are combined in a fixed order by mean_reduce_kernel.
-constexpr int PM_DMAX = 16, PM_PMAX = 16, PM_TJ = 128, PM_QPT = 2;
+// One thread owns QPT queries (coordinates and output accumulators in registers); training rows
+// [x_j / ls (16 slots) | alpha_j (16 slots)] are staged through LDS with a fixed 32-element stride and
+// read as wave-uniform 16-byte broadcasts.  D and P are rounded up to multiples of 4 at compile time
+// (D4, P4 in 1..4; padding slots hold zeros and contribute nothing), so the inner loop is branch-free.
+// The training set is split over gridDim.y; partial sums are combined in a fixed order by
+// mean_reduce_kernel.
+constexpr int PM_DMAX = 16, PM_PMAX = 16, PM_TJ = 128, PM_QPT = 2, PM_RS = PM_DMAX + PM_PMAX;
 
-template <typename T>
+template <typename T> struct Quad;
+template <> struct Quad<float> { typedef float4 type; };
+template <> struct Quad<double> { typedef double4 type; };
+
+template <typename T, int D4, int P4>
 __global__ __launch_bounds__(256) void predict_mean_kernel(const T* __restrict__ X, const T* __restrict__ alpha,
                                                            long long N, int D, int P, Ls16 ls,
                                                            const T* __restrict__ Xq, long long M,
                                                            long long chunk, T* __restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) T rows[PM_TJ * (PM_DMAX + PM_PMAX)];
+  __shared__ __attribute__((aligned(16))) T rows[PM_TJ * PM_RS];
+  typedef typename Quad<T>::type Q4;
   const int tid = threadIdx.x;
-  const int W = D + P;
-  constexpr int RS = PM_DMAX + PM_PMAX;   // fixed row stride: [x(16) | alpha(16)]
-  T xq[PM_QPT][PM_DMAX];
-  T acc[PM_QPT][PM_PMAX];
+  constexpr int DD = 4 * D4, PP = 4 * P4;
+  T xq[PM_QPT][DD];
+  T acc[PM_QPT][PP];
   long long qm[PM_QPT];
 #pragma unroll
   for (int q = 0; q < PM_QPT; ++q) {
     qm[q] = ((long long)blockIdx.x * PM_QPT + q) * 256 + tid;
 #pragma unroll
-    for (int d = 0; d < PM_DMAX; ++d) {
+    for (int d = 0; d < DD; ++d) {
       xq[q][d] = T(0);
       if (d < D && qm[q] < M) xq[q][d] = Xq[qm[q] * D + d] / T(ls.v[d]);
     }
 #pragma unroll
-    for (int p = 0; p < PM_PMAX; ++p) acc[q][p] = T(0);
+    for (int p = 0; p < PP; ++p) acc[q][p] = T(0);
   }
   const long long n0 = (long long)blockIdx.y * chunk;
   const long long n1 = min(N, n0 + chunk);
   for (long long jb = n0; jb < n1; jb += PM_TJ) {
     const int nj = (int)min((long long)PM_TJ, n1 - jb);
     __syncthreads();
-    for (int e = tid; e < nj * W; e += 256) {
-      const int j = e / W, c = e - j * W;
-      if (c < D) rows[j * RS + c] = X[(jb + j) * D + c] / T(ls.v[c]);
-      else rows[j * RS + PM_DMAX + (c - D)] = alpha[(jb + j) * P + (c - D)];
+    // stage [x/ls | 0.. | alpha | 0..] for PM_TJ rows (rows beyond nj are zero-filled: alpha = 0)
+    for (int e = tid; e < PM_TJ * (DD + PP); e += 256) {
+      const int j = e / (DD + PP), c = e - j * (DD + PP);
+      T v = T(0);
+      if (j < nj) {
+        if (c < DD) { if (c < D) v = X[(jb + j) * D + c] / T(ls.v[c]); }
+        else if (c - DD < P) v = alpha[(jb + j) * P + (c - DD)];
+      }
+      rows[j * PM_RS + (c < DD ? c : PM_DMAX + (c - DD))] = v;
     }
     __syncthreads();
-    for (int j = 0; j < nj; ++j) {
-      const T* row = rows + j * RS;
-      T d2[PM_QPT];
+#pragma unroll 2
+    for (int j = 0; j < PM_TJ; ++j) {
+      const Q4* row = reinterpret_cast<const Q4*>(rows + j * PM_RS);
+      T xt[DD], al[PP];
 #pragma unroll
-      for (int q = 0; q < PM_QPT; ++q) d2[q] = T(0);
-#pragma unroll
-      for (int d = 0; d < PM_DMAX; ++d) {
-        if (d < D) {
-          const T xt = row[d];
-#pragma unroll
-          for (int q = 0; q < PM_QPT; ++q) {
-            const T df = xq[q][d] - xt;
-            d2[q] = __builtin_fma(df, df, d2[q]);
-          }
-        }
+      for (int g = 0; g < D4; ++g) {
+        const Q4 v = row[g];
+        xt[4 * g] = v.x; xt[4 * g + 1] = v.y; xt[4 * g + 2] = v.z; xt[4 * g + 3] = v.w;
       }
-      T e[PM_QPT];
 #pragma unroll
-      for (int q = 0; q < PM_QPT; ++q) e[q] = exp_neg(T(-0.5) * d2[q]);
+      for (int g = 0; g < P4; ++g) {
+        const Q4 v = row[PM_DMAX / 4 + g];
+        al[4 * g] = v.x; al[4 * g + 1] = v.y; al[4 * g + 2] = v.z; al[4 * g + 3] = v.w;
+      }
 #pragma unroll
-      for (int p = 0; p < PM_PMAX; ++p) {
-        if (p < P) {
-          const T a = row[PM_DMAX + p];
+      for (int q = 0; q < PM_QPT; ++q) {
+        T d2 = T(0);
 #pragma unroll
-          for (int q = 0; q < PM_QPT; ++q) acc[q][p] = __builtin_fma(e[q], a, acc[q][p]);
+        for (int d = 0; d < DD; ++d) {
+          const T df = xq[q][d] - xt[d];
+          d2 = fma_t(df, df, d2);
         }
+        const T e = exp_neg(T(-0.5) * d2);
+#pragma unroll
+        for (int p = 0; p < PP; ++p) acc[q][p] = fma_t(e, al[p], acc[q][p]);
       }
     }
   }
@@ -297,9 +313,30 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(const T* __restrict__
   for (int q = 0; q < PM_QPT; ++q) {
     if (qm[q] < M) {
 #pragma unroll
-      for (int p = 0; p < PM_PMAX; ++p)
+      for (int p = 0; p < PP; ++p)
         if (p < P) partial[((long long)blockIdx.y * M + qm[q]) * P + p] = acc[q][p];
     }
+  }
+}
+
+template <typename T>
+using pm_fn = void (*)(const T*, const T*, long long, int, int, Ls16, const T*, long long, long long, T*);
+template <typename T, int D4>
+pm_fn<T> pm_pick_p(int p4) {
+  switch (p4) {
+    case 1: return predict_mean_kernel<T, D4, 1>;
+    case 2: return predict_mean_kernel<T, D4, 2>;
+    case 3: return predict_mean_kernel<T, D4, 3>;
+    default: return predict_mean_kernel<T, D4, 4>;
+  }
+}
+template <typename T>
+pm_fn<T> pm_pick(int d4, int p4) {
+  switch (d4) {
+    case 1: return pm_pick_p<T, 1>(p4);
+    case 2: return pm_pick_p<T, 2>(p4);
+    case 3: return pm_pick_p<T, 3>(p4);
+    default: return pm_pick_p<T, 4>(p4);
   }
 }
 
@@ -436,15 +473,16 @@ extern "C" int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const vo
   GPK_TRY(gpk_scratch(h, (size_t)S * M * P * es, &partial));
   dim3 grid((unsigned)nqb, (unsigned)S);
   const int64_t tot = M * P;
+  const int d4 = (D + 3) / 4, p4 = (P + 3) / 4;
   if (dtype == GPK_F64) {
-    hipLaunchKernelGGL(predict_mean_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)X,
+    hipLaunchKernelGGL(pm_pick<double>(d4, p4), grid, dim3(256), 0, h->stream, (const double*)X,
                        (const double*)alpha, (long long)N, D, P, l16, (const double*)Xq, (long long)M,
                        (long long)chunk, (double*)partial);
     GPK_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(mean_reduce_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
                        (const double*)partial, (int)S, (long long)M, P, sf2, ym, ys, (double*)mean);
   } else {
-    hipLaunchKernelGGL(predict_mean_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)X,
+    hipLaunchKernelGGL(pm_pick<float>(d4, p4), grid, dim3(256), 0, h->stream, (const float*)X,
                        (const float*)alpha, (long long)N, D, P, l16, (const float*)Xq, (long long)M,
                        (long long)chunk, (float*)partial);
     GPK_LAUNCH_CHECK(h);

@@ -74,6 +74,7 @@ struct GemmArgs {
   double alpha, beta;
   int lower_only;
   int kb0, kb_row, kb_col, ke0, ke_row, ke_col;
+  int heavy_first;  // process tile rows in reverse order (use when the k-range grows with the tile row)
   int epilogue;   // 0: store C;  1: C (fp64, ld = ldc) [tile_row][col] = sum over the tile's rows of (alpha*acc)^2
 };
 inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb,
@@ -81,7 +82,7 @@ inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.m = m; g.n = n; g.k = k; g.ta = ta; g.tb = tb; g.alpha = alpha; g.beta = beta;
-  g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0; g.epilogue = 0;
+  g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0; g.epilogue = 0; g.heavy_first = 0;
   return g;
 }
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);
