@@ -1,4 +1,6 @@
 // Context management and the composite entry points of the libgpk C ABI.
+#include <cstdlib>
+
 #include "gpk_internal.h"
 
 extern "C" const char* gpk_version(void) { return "gpk 0.1 (gfx950)"; }
@@ -21,6 +23,8 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
     return GPK_HIP_ERROR;
   }
   h->stream = h->own_stream;
+  if (const char* e = getenv("GPK_GEMM_WM_F64")) h->gemm_wm_f64 = (e[0] == '2') ? 2 : 4;
+  if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
   *out = h;
   return GPK_OK;
 }

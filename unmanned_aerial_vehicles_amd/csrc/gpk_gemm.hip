@@ -47,137 +47,150 @@ struct KParams {
 typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
 
 // ---- global -> registers: 4 x 16 B per thread per operand -------------------------------
-template <typename T, bool TR>
+// NT = threads per workgroup (256 or 512); an operand k-tile is 1024 chunks of 16 bytes, NP per thread
+template <typename T, bool TR, int NT>
 __device__ __forceinline__ void load_tile(const T* __restrict__ base, long long ld, int row0, int k0,
-                                          int tid, V16 (&r)[4]) {
+                                          int tid, V16 (&r)[1024 / NT]) {
   constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+  constexpr int NP = 1024 / NT;
   if constexpr (!TR) {
-    // stored (rows x k): thread -> chunk c of row (tid>>3) + 32p
+    // stored (rows x k): thread -> chunk c of row (tid>>3) + (NT/8) p
     const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const T* g = base + (long long)(row0 + rr + 32 * p) * ld + k0 + c * EPC;
+    for (int p = 0; p < NP; ++p) {
+      const T* g = base + (long long)(row0 + rr + (NT / 8) * p) * ld + k0 + c * EPC;
       r[p] = *reinterpret_cast<const V16*>(g);
     }
   } else {
     // stored (k x rows): BK k-rows of 128 elements
     constexpr int CPR = 128 / EPC;       // chunks per k-row: 64 (f64) / 32 (f32)
-    constexpr int RPP = 256 / CPR;       // k-rows per pass: 4 / 8
+    constexpr int RPP = NT / CPR;        // k-rows per pass
     const int c = tid % CPR, kr = tid / CPR;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const T* g = base + (long long)(k0 + kr + RPP * p) * ld + row0 + c * EPC;
       r[p] = *reinterpret_cast<const V16*>(g);
     }
   }
 }
 
-template <typename T, bool TR>
-__device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[4]) {
+template <typename T, bool TR, int NT>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[1024 / NT]) {
   constexpr int EPC = 16 / sizeof(T);
+  constexpr int NP = 1024 / NT;
   if constexpr (!TR) {
     const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      *reinterpret_cast<V16*>(lds + (rr + 32 * p) * LDS_N_STRIDE + c * 16) = r[p];
+    for (int p = 0; p < NP; ++p)
+      *reinterpret_cast<V16*>(lds + (rr + (NT / 8) * p) * LDS_N_STRIDE + c * 16) = r[p];
   } else {
     constexpr int CPR = 128 / EPC;
-    constexpr int RPP = 256 / CPR;
+    constexpr int RPP = NT / CPR;
     constexpr int RS = Cfg<T>::T_STRIDE * sizeof(T);
     const int c = tid % CPR, kr = tid / CPR;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < NP; ++p)
       *reinterpret_cast<V16*>(lds + (kr + RPP * p) * RS + c * 16) = r[p];
   }
 }
 
-// ---- fp64: 4 x 4 blocks of 16x16x4 per wave ------------------------------------------------
-template <bool TA, bool TB>
+// ---- fp64: AB x 4 blocks of 16x16x4 per wave (wave tile 16 AB rows x 64 columns) ------------------
+template <bool TA, bool TB, int AB>
 __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane,
-                                             d4 (&acc)[4][4]) {
+                                             d4 (&acc)[AB][4]) {
   const int r = lane & 15, kq = lane >> 4;
   constexpr int RS = Cfg<double>::T_STRIDE * 8;
+  constexpr int RW = 16 * AB;
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
-    double af[4][2], bf[4][2];
+    double af[AB][2], bf[4][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < AB; ++a) {
       if constexpr (!TA) {
-        const double2 v = *reinterpret_cast<const double2*>(la + (wm * 64 + 16 * a + r) * LDS_N_STRIDE +
+        const double2 v = *reinterpret_cast<const double2*>(la + (wm * RW + 16 * a + r) * LDS_N_STRIDE +
                                                             (4 * kq + 2 * hh) * 8);
         af[a][0] = v.x; af[a][1] = v.y;
       } else {
-        af[a][0] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh) * RS + (wm * 64 + 16 * a + r) * 8);
-        af[a][1] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh + 1) * RS + (wm * 64 + 16 * a + r) * 8);
+        af[a][0] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh) * RS + (wm * RW + 16 * a + r) * 8);
+        af[a][1] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh + 1) * RS + (wm * RW + 16 * a + r) * 8);
       }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
       if constexpr (!TB) {
-        const double2 v = *reinterpret_cast<const double2*>(lb + (wn * 64 + 16 * a + r) * LDS_N_STRIDE +
+        const double2 v = *reinterpret_cast<const double2*>(lb + (wn * 64 + 16 * b + r) * LDS_N_STRIDE +
                                                             (4 * kq + 2 * hh) * 8);
-        bf[a][0] = v.x; bf[a][1] = v.y;
+        bf[b][0] = v.x; bf[b][1] = v.y;
       } else {
-        bf[a][0] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh) * RS + (wn * 64 + 16 * a + r) * 8);
-        bf[a][1] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh + 1) * RS + (wn * 64 + 16 * a + r) * 8);
+        bf[b][0] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh) * RS + (wn * 64 + 16 * b + r) * 8);
+        bf[b][1] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh + 1) * RS + (wn * 64 + 16 * b + r) * 8);
       }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < AB; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
   }
 }
 
-// ---- fp32: 2 x 2 blocks of 32x32x2 per wave -------------------------------------------------
-template <bool TA, bool TB>
+// ---- fp32: AB x 2 blocks of 32x32x2 per wave (wave tile 32 AB rows x 64 columns) --------------------
+template <bool TA, bool TB, int AB>
 __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane,
-                                             f16v (&acc)[2][2]) {
+                                             f16v (&acc)[AB][2]) {
   const int r = lane & 31, kq = lane >> 5;
   constexpr int RS = Cfg<float>::T_STRIDE * 4;
+  constexpr int RW = 32 * AB;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // 4 groups of 4 k-steps
-    float af[2][4], bf[2][4];
+    float af[AB][4], bf[2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < AB; ++a) {
       if constexpr (!TA) {
-        const float4 v = *reinterpret_cast<const float4*>(la + (wm * 64 + 32 * a + r) * LDS_N_STRIDE +
+        const float4 v = *reinterpret_cast<const float4*>(la + (wm * RW + 32 * a + r) * LDS_N_STRIDE +
                                                           (16 * kq + 4 * q) * 4);
         af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          af[a][t] = *reinterpret_cast<const float*>(la + (16 * kq + 4 * q + t) * RS + (wm * 64 + 32 * a + r) * 4);
+          af[a][t] = *reinterpret_cast<const float*>(la + (16 * kq + 4 * q + t) * RS + (wm * RW + 32 * a + r) * 4);
       }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
       if constexpr (!TB) {
-        const float4 v = *reinterpret_cast<const float4*>(lb + (wn * 64 + 32 * a + r) * LDS_N_STRIDE +
+        const float4 v = *reinterpret_cast<const float4*>(lb + (wn * 64 + 32 * b + r) * LDS_N_STRIDE +
                                                           (16 * kq + 4 * q) * 4);
-        bf[a][0] = v.x; bf[a][1] = v.y; bf[a][2] = v.z; bf[a][3] = v.w;
+        bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          bf[a][t] = *reinterpret_cast<const float*>(lb + (16 * kq + 4 * q + t) * RS + (wn * 64 + 32 * a + r) * 4);
+          bf[b][t] = *reinterpret_cast<const float*>(lb + (16 * kq + 4 * q + t) * RS + (wn * 64 + 32 * b + r) * 4);
       }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < AB; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
   }
 }
 
-__device__ __forceinline__ void zero_acc(d4 (&acc)[4][4]) {
+template <int AB>
+__device__ __forceinline__ void zero_acc(d4 (&acc)[AB][4]) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < AB; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 }
-__device__ __forceinline__ void zero_acc(f16v (&acc)[2][2]) {
+template <int AB>
+__device__ __forceinline__ void zero_acc(f16v (&acc)[AB][2]) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < AB; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -186,16 +199,17 @@ __device__ __forceinline__ void zero_acc(f16v (&acc)[2][2]) {
 
 // C/D maps: f64 16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg;
 //           f32 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <int AB>
 __device__ __forceinline__ void store_acc(double* __restrict__ C, long long ldc, int row0, int col0,
-                                          int wm, int wn, int lane, const d4 (&acc)[4][4], double alpha,
+                                          int wm, int wn, int lane, const d4 (&acc)[AB][4], double alpha,
                                           double beta) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < AB; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wm * 64 + 16 * a + (lane >> 4) + 4 * i;
+        const int row = row0 + wm * 16 * AB + 16 * a + (lane >> 4) + 4 * i;
         const int col = col0 + wn * 64 + 16 * b + (lane & 15);
         double* p = C + (long long)row * ldc + col;
         double v = alpha * acc[a][b][i];
@@ -203,17 +217,18 @@ __device__ __forceinline__ void store_acc(double* __restrict__ C, long long ldc,
         *p = v;
       }
 }
+template <int AB>
 __device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, int row0, int col0,
-                                          int wm, int wn, int lane, const f16v (&acc)[2][2], double alpha,
+                                          int wm, int wn, int lane, const f16v (&acc)[AB][2], double alpha,
                                           double beta) {
   const float al = (float)alpha, be = (float)beta;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < AB; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = row0 + wm * 64 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int row = row0 + wm * 32 * AB + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
         const int col = col0 + wn * 64 + 32 * b + (lane & 31);
         float* p = C + (long long)row * ldc + col;
         float v = al * acc[a][b][i];
@@ -222,20 +237,18 @@ __device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, 
       }
 }
 
-template <typename T> struct AccT;
-template <> struct AccT<double> { typedef d4 type[4][4]; };
-template <> struct AccT<float> { typedef f16v type[2][2]; };
-
 // Epilogue 1 (column sums of squares): instead of storing the 128 x 128 tile, store for each of its
 // 128 columns the sum over the tile's rows of (alpha * acc)^2, in fp64, at C[tile_row * ldc + col].
+// WM = wave rows of the workgroup (each contributes a partial per column).
+template <int AB, int WM>
 __device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, long long ldo, int tm, int col0,
-                                          int wm, int wn, int lane, int tid, const d4 (&acc)[4][4], double alpha) {
-  double* red = reinterpret_cast<double*>(lds);   // [2][128]
+                                          int wm, int wn, int lane, int tid, const d4 (&acc)[AB][4], double alpha) {
+  double* red = reinterpret_cast<double*>(lds);   // [WM][128]
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     double s = 0.0;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < AB; ++a)
 #pragma unroll
       for (int i = 0; i < 4; ++i) { const double v = alpha * acc[a][b][i]; s = __builtin_fma(v, v, s); }
     s += __shfl_xor(s, 16, 64);
@@ -243,30 +256,50 @@ __device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, l
     if (lane < 16) red[wm * 128 + wn * 64 + 16 * b + lane] = s;
   }
   __syncthreads();
-  if (tid < 128) out[(long long)tm * ldo + col0 + tid] = red[tid] + red[128 + tid];
+  if (tid < 128) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) t += red[w * 128 + tid];
+    out[(long long)tm * ldo + col0 + tid] = t;
+  }
 }
+template <int AB, int WM>
 __device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, long long ldo, int tm, int col0,
-                                          int wm, int wn, int lane, int tid, const f16v (&acc)[2][2], double alpha) {
+                                          int wm, int wn, int lane, int tid, const f16v (&acc)[AB][2], double alpha) {
   double* red = reinterpret_cast<double*>(lds);
   const float al = (float)alpha;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     float s = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AB; ++a)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { const float v = al * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) red[wm * 128 + wn * 64 + 32 * b + lane] = (double)s;
   }
   __syncthreads();
-  if (tid < 128) out[(long long)tm * ldo + col0 + tid] = red[tid] + red[128 + tid];
+  if (tid < 128) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) t += red[w * 128 + tid];
+    out[(long long)tm * ldo + col0 + tid] = t;
+  }
 }
 
-template <typename T, bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
+// accumulator block grid per wave: rows of the wave tile / MFMA block rows
+template <typename T, int WM> struct AccT;
+template <int WM> struct AccT<double, WM> { static constexpr int AB = 128 / WM / 16; typedef d4 type[AB][4]; };
+template <int WM> struct AccT<float, WM> { static constexpr int AB = 128 / WM / 32; typedef f16v type[AB][2]; };
+
+// WM wave rows x 2 wave columns: WM = 2 -> 256 threads, 64 x 64 per wave, 2 waves/SIMD at 2 workgroups/CU;
+//                                WM = 4 -> 512 threads, 32 x 64 per wave, 4 waves/SIMD (<= 128 VGPRs)
+template <typename T, bool TA, bool TB, int EPI, int WM>
+__global__ __launch_bounds__(WM * 128, WM) void gemm_kernel(KParams p) {
   __shared__ __attribute__((aligned(16))) char lds[4 * LDS_OP_BYTES];
   constexpr int BK = Cfg<T>::BK;
+  constexpr int NT = WM * 128;
+  constexpr int AB = AccT<T, WM>::AB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -313,46 +346,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(KParams p) {
   T* C = reinterpret_cast<T*>(p.C);
   const int row0 = tm * BM, col0 = tn * BN;
 
-  typename AccT<T>::type acc;
-  zero_acc(acc);
+  typename AccT<T, WM>::type acc;
+  zero_acc<AB>(acc);
 
   if (nkt > 0) {
     // Register-staged software pipeline ("write after the barrier"): at the top of iteration kt the
     // registers hold k-tile kt+1 (fetched during iteration kt-1's MFMAs); they are written to the
     // idle LDS buffer, the fetch of k-tile kt+2 is issued, and the MFMAs of k-tile kt run while it
     // is in flight.  One barrier per k-tile; tile indices are clamped so the body is branch-free.
-    V16 ra[4], rb[4];
-    load_tile<T, TA>(A, p.lda, row0, kb, tid, ra);
-    load_tile<T, TB>(B, p.ldb, col0, kb, tid, rb);
-    store_tile<T, TA>(lds, tid, ra);
-    store_tile<T, TB>(lds + LDS_OP_BYTES, tid, rb);
+    V16 ra[1024 / NT], rb[1024 / NT];
+    load_tile<T, TA, NT>(A, p.lda, row0, kb, tid, ra);
+    load_tile<T, TB, NT>(B, p.ldb, col0, kb, tid, rb);
+    store_tile<T, TA, NT>(lds, tid, ra);
+    store_tile<T, TB, NT>(lds + LDS_OP_BYTES, tid, rb);
     {
       const int k1 = min(1, nkt - 1);
-      load_tile<T, TA>(A, p.lda, row0, kb + k1 * BK, tid, ra);
-      load_tile<T, TB>(B, p.ldb, col0, kb + k1 * BK, tid, rb);
+      load_tile<T, TA, NT>(A, p.lda, row0, kb + k1 * BK, tid, ra);
+      load_tile<T, TB, NT>(B, p.ldb, col0, kb + k1 * BK, tid, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int cur = kt & 1;
-      store_tile<T, TA>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
-      store_tile<T, TB>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
+      store_tile<T, TA, NT>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
+      store_tile<T, TB, NT>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
       const int kn = min(kt + 2, nkt - 1);
-      load_tile<T, TA>(A, p.lda, row0, kb + kn * BK, tid, ra);
-      load_tile<T, TB>(B, p.ldb, col0, kb + kn * BK, tid, rb);
-      compute_tile<TA, TB>(lds + cur * 2 * LDS_OP_BYTES, lds + cur * 2 * LDS_OP_BYTES + LDS_OP_BYTES, wm, wn,
+      load_tile<T, TA, NT>(A, p.lda, row0, kb + kn * BK, tid, ra);
+      load_tile<T, TB, NT>(B, p.ldb, col0, kb + kn * BK, tid, rb);
+      compute_tile<TA, TB, AB>(lds + cur * 2 * LDS_OP_BYTES, lds + cur * 2 * LDS_OP_BYTES + LDS_OP_BYTES, wm, wn,
                            lane, acc);
       __syncthreads();
     }
   }
   if constexpr (EPI == 0) {
-    store_acc(C, p.ldc, row0, col0, wm, wn, lane, acc, p.alpha, p.beta);
+    store_acc<AB>(C, p.ldc, row0, col0, wm, wn, lane, acc, p.alpha, p.beta);
   } else {
     // the k-loop ended with a barrier: the staging buffers are free for the reduction
-    sumsq_acc(lds, reinterpret_cast<double*>(p.C), p.ldc, tm, col0, wm, wn, lane, tid, acc, p.alpha);
+    sumsq_acc<AB, WM>(lds, reinterpret_cast<double*>(p.C), p.ldc, tm, col0, wm, wn, lane, tid, acc, p.alpha);
   }
 }
 
-template <typename T>
+template <typename T, int WM>
 int launch(gpk_handle h, const GemmArgs& g) {
   KParams p;
   p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
@@ -376,18 +409,18 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.nst = g.lower_only ? nsr * (nsr + 1) / 2 : nsr * p.nsc;
   const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
   if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
-  dim3 grid((unsigned)nblocks), block(256);
+  dim3 grid((unsigned)nblocks), block(WM * 128);
   if (g.epilogue == 1) {
     if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }
-    if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<T, false, true, 1>), grid, block, 0, h->stream, p);
+    if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1, WM>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, false, true, 1, WM>), grid, block, 0, h->stream, p);
     GPK_LAUNCH_CHECK(h);
     return GPK_OK;
   }
-  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 0>), grid, block, 0, h->stream, p);
-  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, 0>), grid, block, 0, h->stream, p);
-  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, 0>), grid, block, 0, h->stream, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, true, true, 0>), grid, block, 0, h->stream, p);
+  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 0, WM>), grid, block, 0, h->stream, p);
+  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, 0, WM>), grid, block, 0, h->stream, p);
+  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, 0, WM>), grid, block, 0, h->stream, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true, 0, WM>), grid, block, 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }
@@ -404,5 +437,8 @@ int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   const int es = dtype == GPK_F64 ? 8 : 4;
   GPK_REQUIRE(h, (g.lda * es) % 16 == 0 && (g.ldb * es) % 16 == 0, "gemm: leading dimensions must be 16-byte multiples");
   GPK_REQUIRE(h, ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: operands must be 16-byte aligned");
-  return dtype == GPK_F64 ? launch<double>(h, g) : launch<float>(h, g);
+  // wave rows per workgroup (2 -> 256 threads, 4 -> 512 threads), per dtype; tuned on MI355X,
+  // overridable through GPK_GEMM_WM_F64 / GPK_GEMM_WM_F32 (read once per handle)
+  if (dtype == GPK_F64) return h->gemm_wm_f64 == 2 ? launch<double, 2>(h, g) : launch<double, 4>(h, g);
+  return h->gemm_wm_f32 == 2 ? launch<float, 2>(h, g) : launch<float, 4>(h, g);
 }

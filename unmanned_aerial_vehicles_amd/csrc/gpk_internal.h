@@ -21,6 +21,8 @@ struct gpk_context {
   int* d_info = nullptr;        // device int for potrf pivot failures
   double* d_small = nullptr;    // 4 KiB device doubles for reductions
   double* h_small = nullptr;    // pinned host mirror
+  int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
+  int gemm_wm_f32 = 4;
 };
 
 #define GPK_CHECK_HIP(h, call)                                                          \
