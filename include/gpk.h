@@ -115,6 +115,15 @@ int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, 
                      int P, const double* ls, double sf2, const double* y_mean,
                      const double* y_std, const void* Xq, int64_t M, void* mean);
 
+/* K4 for B (<= 8) independent single-output ARD models that share X (the per-axis GPs of
+ * src/px4/gp_trainer.py:139-179, predicted one by one at src/px4/pretrained_gp.py:64-91): one launch
+ * evaluates every model; the feature differences of a (query, training point) pair are formed once.
+ * alpha: dev (N x B), column b = model b; ls: host double[B*D] (row b = model b's ARD length-scales);
+ * sf2, y_mean, y_std: host double[B]; mean: dev (M x B).  X, alpha, Xq, mean of `dtype`.  D <= 16.      */
+int gpk_predict_mean_multi(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
+                           int B, const double* ls, const double* sf2, const double* y_mean,
+                           const double* y_std, const void* Xq, int64_t M, void* mean);
+
 /* ---- K5: posterior variance ---------------------------------------------------------------
  * var[m] = max(kss - sum_i (L^-1 k*_m)_i^2, floor) in units of the normalised targets
  * (caller multiplies by y_std^2).  kss = sf2 (+ noise for the sklearn surface).

@@ -38,6 +38,10 @@ def test_fixed_theta_vs_sklearn(csv_data, ka, name, D, cols, ls, noise):
     assert g.n_features_in_ == D and g.X_train_.shape == X.shape
     mean_only = g.predict(Xq)
     assert np.array_equal(mean_only, mean)
+    g.var_method = "solve"                      # the reference's solve_triangular form
+    mean_s, std_s = g.predict(Xq, return_std=True)
+    assert np.array_equal(mean_s, mean) and relerr(std_s, ka[f"{name}_std"]) < TOL
+    g.var_method = "auto"
     if name != "ka1":
         lml, grad = g.log_marginal_likelihood(g.kernel_.theta, eval_gradient=True)
         assert abs(lml - ka[f"{name}_lml"]) < 1e-10 * abs(lml)
@@ -262,3 +266,35 @@ def test_full_size_properties():
                 lij = float(np.dot(Lr[a, : j + 1], Lr[b, : j + 1]))
                 kij = float(O.rbf_gram(X[[i, j]], 2.0, 1.0)[0, 1]) if i != j else 1.0 + s
                 assert abs(lij - kij) < 1e-11
+
+
+def test_batched_per_axis_ard_gps(csv_data, ka):
+    """BASELINE config 5: 3 per-axis ARD GPs sharing X — fused one-launch mean vs the per-model path and
+    vs scikit-learn (KA6b is the dvx model at the same fixed theta), LML + gradient per model."""
+    from unmanned_aerial_vehicles_amd import BatchedARDGP
+    X, Y, Xq = csv_data["X10"][:, :9], csv_data["Y6"][:, 3:6], csv_data["Xq10"][:, :9]
+    for concurrent in (False, True):
+        bg = BatchedARDGP(length_scale=ka["ka6b_ls"], noise_level=0.05, alpha=1e-6, normalize_y=False,
+                          optimizer=None, concurrent=concurrent).fit(X, Y)
+        mean = bg.predict(Xq)
+        assert mean.shape == (64, 3)
+        assert relerr(mean[:, 0], ka["ka6b_mean"]) < TOL
+        per_model = np.stack([m.predict(Xq) for m in bg.models], axis=1)
+        assert relerr(mean, per_model) < 1e-12
+        mean2, std = bg.predict(Xq, return_std=True)
+        assert relerr(std[:, 0], ka["ka6b_std"]) < TOL
+        lml, grad = bg.log_marginal_likelihood(bg.thetas, eval_gradient=True)
+        assert lml.shape == (3,) and grad.shape == (3, 10)
+        assert abs(lml[0] - ka["ka6b_lml"]) < 1e-10 * abs(lml[0])
+        assert relerr(grad[0], ka["ka6b_grad"]) < 1e-8
+    # fp32 fused predict
+    bg.predict_dtype = "float32"
+    bg._fused = None
+    assert relerr(bg.predict(Xq), mean) < 2e-4
+    # different hyper-parameters per model really are used
+    bg2 = BatchedARDGP(length_scale=ka["ka6b_ls"], noise_level=0.05, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, Y)
+    bg2.models[1].kernel_.theta = bg2.models[1].kernel_.theta + 0.4
+    bg2.models[1]._refactor()
+    bg2._fused = None
+    ref1 = bg2.models[1].predict(Xq)
+    assert relerr(bg2.predict(Xq)[:, 1], ref1) < 1e-12

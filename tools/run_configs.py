@@ -142,8 +142,27 @@ def main():
             gb._dev.release_grad_buffers()
             del gb
         # N^3/3 (potrf) + N^3/3 (trtri) + N^3/3 (W^T W) flops per evaluation
-        c5[f"N{N5}"] = {"lml_grad_eval_s_per_gp": times, "three_gps_s": sum(times),
+        c5[f"N{N5}"] = {"lml_grad_eval_s_per_gp": times, "three_gps_sequential_s": sum(times),
                         "TFLOPs_per_eval": N5 ** 3 / np.mean(times) / 1e12, "lml": lmls}
+        # the batched surface: 3 models on 3 streams/handles, fused one-launch mean for 10 000 queries
+        from unmanned_aerial_vehicles_amd import BatchedARDGP
+        bg = BatchedARDGP(length_scale=ls, noise_level=0.1, alpha=1e-4, normalize_y=True, optimizer=None,
+                          predict_dtype="float32").fit(X, Y)
+        th = bg.thetas
+        t, (bl, bgr) = wall(lambda: bg.log_marginal_likelihood(th, eval_gradient=True), reps=2)
+        c5[f"N{N5}"]["three_gps_concurrent_s"] = t
+        c5[f"N{N5}"]["lml_batched_matches"] = bool(np.allclose(bl, lmls, rtol=1e-12))
+        Xq5 = np.random.default_rng(1).standard_normal((10000, 9))
+        q5 = torch.as_tensor(Xq5, dtype=torch.float32, device=be.device)
+        bg.predict_mean_dev(q5)
+        t, _ = wall(lambda: bg.predict_mean_dev(q5), reps=5)
+        c5[f"N{N5}"]["fused_3gp_mean_10k_queries_ms"] = t * 1e3
+        for m in bg.models:
+            m.predict_dtype = "float32"
+        t, _ = wall(lambda: [m._dev.predict_mean_dev(q5, m._y_train_mean, m._y_train_std, "float32") for m in bg.models],
+                    reps=5)
+        c5[f"N{N5}"]["per_model_3gp_mean_10k_queries_ms"] = t * 1e3
+        del bg
         if have_skl and N5 == 4096:
             from sklearn.gaussian_process.kernels import ConstantKernel as SkC
             kern = SkC(1.0, "fixed") * SkRBF(ls, (0.1, 10.0)) + SkWhite(0.1, (1e-5, 1e1))

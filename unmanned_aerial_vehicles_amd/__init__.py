@@ -14,9 +14,10 @@ from .gpr import GaussianProcessRegressor  # noqa: F401
 from .simple_gp import SimpleGPEnhancedMPC, SimpleQuadrotorGP  # noqa: F401
 from .package_gp import GaussianProcess  # noqa: F401
 from .trainer import GPTrainer, PreTrainedGP  # noqa: F401
+from .batched import BatchedARDGP  # noqa: F401
 from .evaluate import evaluate_gp  # noqa: F401
 from .sharded import ShardedPredictor, shard_bounds, sharded_predict  # noqa: F401
 
 __all__ = ["GaussianProcessRegressor", "RBF", "WhiteKernel", "ConstantKernel", "SimpleQuadrotorGP",
            "SimpleGPEnhancedMPC", "GaussianProcess", "GPTrainer", "PreTrainedGP", "evaluate_gp",
-           "ShardedPredictor", "shard_bounds", "sharded_predict"]
+           "ShardedPredictor", "shard_bounds", "sharded_predict", "BatchedARDGP"]

@@ -37,6 +37,7 @@ SIGNATURES = {
     "gpk_trsm_lower_left": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _vp, _i64, _i64]),
     "gpk_colsumsq": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp]),
     "gpk_predict_mean": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _vp]),
+    "gpk_predict_mean_multi": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,
                                _dbl, _vp, _vp]),
     "gpk_trtri": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),

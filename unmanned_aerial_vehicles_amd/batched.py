@@ -1,0 +1,163 @@
+"""B independent single-output ARD GPs that share their training inputs (BASELINE config 5: the per-axis
+ax/ay/az models of `src/px4/gp_trainer.py:139-179`, one `C(1,fixed)*RBF(ls in R^D)+WhiteKernel` GP per
+output).
+
+* training / hyper-parameter steps: the B factorisations are independent, so each model runs on its own
+  libgpk handle and HIP stream from a worker thread (ctypes releases the GIL) — at the small and medium
+  N of this use case a single model's launch chain cannot fill 256 CUs, the B chains overlap;
+* prediction: ONE fused launch evaluates all B posterior means (`gpk_predict_mean_multi`): the feature
+  differences of a (query, training point) pair are formed once and reused by every model.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _lib
+from .device import Backend, get_backend
+from .gpr import GaussianProcessRegressor
+from .kernels import RBF, ConstantKernel, WhiteKernel
+
+
+class BatchedARDGP:
+    def __init__(self, length_scale=1.0, length_scale_bounds=(0.1, 10.0), noise_level=0.01,
+                 noise_level_bounds=(1e-5, 1e1), alpha=1e-6, normalize_y=True, optimizer="fmin_l_bfgs_b",
+                 n_restarts_optimizer=0, device=None, predict_dtype="float64", concurrent=True):
+        self.length_scale, self.length_scale_bounds = length_scale, length_scale_bounds
+        self.noise_level, self.noise_level_bounds = noise_level, noise_level_bounds
+        self.alpha, self.normalize_y = alpha, normalize_y
+        self.optimizer, self.n_restarts_optimizer = optimizer, n_restarts_optimizer
+        self.device, self.predict_dtype, self.concurrent = device, predict_dtype, concurrent
+        self.models = []
+        self._workers = []
+        self._fused = None
+
+    # ------------------------------------------------------------------ workers
+    def _backend(self, b):
+        import torch
+        main = get_backend(self.device)
+        if not self.concurrent:
+            return main, None
+        while len(self._workers) <= b:
+            self._workers.append((Backend(main.device_index), torch.cuda.Stream(device=main.device)))
+        return self._workers[b]
+
+    def _map(self, fn, n):
+        """Run fn(b) for b in range(n); concurrently (one stream + handle per model) when enabled."""
+        import torch
+        if not self.concurrent or n == 1:
+            return [fn(b) for b in range(n)]
+
+        def run(b):
+            be, stream = self._backend(b)
+            with torch.cuda.stream(stream):
+                out = fn(b)
+                stream.synchronize()
+            return out
+
+        for b in range(n):
+            self._backend(b)
+        torch.cuda.current_stream().synchronize()
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            return list(ex.map(run, range(n)))
+
+    def _kernel(self, D):
+        ls = np.broadcast_to(np.asarray(self.length_scale, dtype=np.float64), (D,)).copy()
+        return (ConstantKernel(1.0, constant_value_bounds="fixed") * RBF(ls, self.length_scale_bounds)
+                + WhiteKernel(self.noise_level, self.noise_level_bounds))
+
+    # ------------------------------------------------------------------ fit / LML
+    def fit(self, X, Y):
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64).reshape(len(X), -1)
+        B, D = Y.shape[1], X.shape[1]
+        if B > 8:
+            raise ValueError("at most 8 models per batch")
+
+        def one(b):
+            be = self._backend(b)[0]
+            g = GaussianProcessRegressor(kernel=self._kernel(D), alpha=self.alpha, normalize_y=self.normalize_y,
+                                         optimizer=self.optimizer, n_restarts_optimizer=self.n_restarts_optimizer,
+                                         device=be, predict_dtype=self.predict_dtype)
+            return g.fit(X, Y[:, b])
+
+        self.models = self._map(one, B)
+        self._fused = None
+        return self
+
+    def log_marginal_likelihood(self, thetas, eval_gradient=False):
+        """thetas: (B, D+1) log-parameters [log ls_0..log ls_{D-1}, log noise] per model.
+        Returns lml (B,) and, with eval_gradient, grad (B, D+1) — the hyper-parameter step of config 5."""
+        thetas = np.asarray(thetas, dtype=np.float64)
+
+        def one(b):
+            g = self.models[b]
+            out = g._lml_on_device(thetas[b], eval_gradient)
+            g._refactor()
+            return out
+
+        res = self._map(one, len(self.models))
+        if not eval_gradient:
+            return np.array(res)
+        return np.array([r[0] for r in res]), np.stack([r[1] for r in res])
+
+    @property
+    def thetas(self):
+        return np.stack([m.kernel_.theta for m in self.models])
+
+    # ------------------------------------------------------------------ predict
+    def _build_fused(self):
+        import torch
+        m0 = self.models[0]
+        for m in self.models:
+            m._ensure_device()
+        be = get_backend(self.device)
+        f32 = self.predict_dtype == "float32"
+        tdt = torch.float32 if f32 else torch.float64
+        comps = [m.kernel_.components() for m in self.models]
+        D = m0.n_features_in_
+        with torch.cuda.device(be.device):
+            torch.cuda.synchronize()
+            alpha = torch.stack([m._dev.alpha[:, 0].to(be.device) for m in self.models], dim=1).to(tdt).contiguous()
+            X = m0._dev.X.to(be.device).to(tdt).contiguous()
+        self._fused = {
+            "X": X, "alpha": alpha, "N": X.shape[0], "D": D, "tdt": tdt, "code": _lib.GPK_F32 if f32 else _lib.GPK_F64,
+            "ls": np.ascontiguousarray(np.stack([c.ls_vector(D) for c in comps])),
+            "sf2": np.ascontiguousarray([c.sf2 for c in comps], dtype=np.float64),
+            "ym": np.ascontiguousarray([m._y_train_mean[0] for m in self.models], dtype=np.float64),
+            "ys": np.ascontiguousarray([m._y_train_std[0] for m in self.models], dtype=np.float64),
+        }
+
+    def predict_mean_dev(self, Xq):
+        """All B posterior means in one kernel launch; returns a (M, B) device tensor."""
+        import torch
+        if self._fused is None:
+            self._build_fused()
+        f = self._fused
+        be = get_backend(self.device)
+        if isinstance(Xq, torch.Tensor):
+            q = Xq.to(device=be.device, dtype=f["tdt"]).contiguous()
+        else:
+            q = be.upload(np.ascontiguousarray(Xq, dtype=np.float64), f["tdt"])
+        M, B = q.shape[0], len(self.models)
+        out = be.empty((M, B), f["tdt"])
+        if M == 0:
+            return out
+        dp = _lib._dp
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_predict_mean_multi(
+                be.h, f["code"], C.c_void_p(f["X"].data_ptr()), C.c_void_p(f["alpha"].data_ptr()), f["N"], f["D"], B,
+                f["ls"].ctypes.data_as(dp), f["sf2"].ctypes.data_as(dp), f["ym"].ctypes.data_as(dp),
+                f["ys"].ctypes.data_as(dp), C.c_void_p(q.data_ptr()), M, C.c_void_p(out.data_ptr())))
+        return out
+
+    def predict(self, Xq, return_std=False):
+        Xq = np.atleast_2d(np.asarray(Xq, dtype=np.float64))
+        mean = self.predict_mean_dev(Xq).double().cpu().numpy()
+        if not return_std:
+            return mean
+        std = np.stack(self._map(lambda b: self.models[b].predict(Xq, return_std=True)[1], len(self.models)), axis=1)
+        return mean, std

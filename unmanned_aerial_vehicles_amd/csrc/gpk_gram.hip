@@ -340,6 +340,121 @@ pm_fn<T> pm_pick(int d4, int p4) {
   }
 }
 
+// ---- K4, multi-model form: B independent ARD GPs (own length-scales, signal variance and alpha)
+// that share the training inputs X, evaluated in one launch: per (query, training point) pair the
+// feature differences are formed once and reused by every model.  Rows are staged as
+// [x raw (16 slots) | alpha_0..alpha_{B-1} (16 slots)]; the per-model weights 1/ls^2 live in LDS.
+template <typename T, int D4, int B4>
+__global__ __launch_bounds__(256) void predict_mean_multi_kernel(const T* __restrict__ X,
+                                                                 const T* __restrict__ alpha, long long N, int D,
+                                                                 int B, const double* __restrict__ w_dev,
+                                                                 const T* __restrict__ Xq, long long M,
+                                                                 long long chunk, T* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) T rows[PM_TJ * PM_RS];
+  __shared__ __attribute__((aligned(16))) T wl[4 * B4 * 4 * D4];     // [b][d] = 1 / ls_bd^2 (0 in the padding)
+  typedef typename Quad<T>::type Q4;
+  const int tid = threadIdx.x;
+  constexpr int DD = 4 * D4, BB = 4 * B4;
+  for (int e = tid; e < BB * DD; e += 256) {
+    const int b = e / DD, d = e - b * DD;
+    wl[e] = (b < B && d < D) ? T(w_dev[b * D + d]) : T(0);
+  }
+  T xq[PM_QPT][DD];
+  T acc[PM_QPT][BB];
+  long long qm[PM_QPT];
+#pragma unroll
+  for (int q = 0; q < PM_QPT; ++q) {
+    qm[q] = ((long long)blockIdx.x * PM_QPT + q) * 256 + tid;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+      xq[q][d] = T(0);
+      if (d < D && qm[q] < M) xq[q][d] = Xq[qm[q] * D + d];
+    }
+#pragma unroll
+    for (int b = 0; b < BB; ++b) acc[q][b] = T(0);
+  }
+  const long long n0 = (long long)blockIdx.y * chunk;
+  const long long n1 = min(N, n0 + chunk);
+  for (long long jb = n0; jb < n1; jb += PM_TJ) {
+    const int nj = (int)min((long long)PM_TJ, n1 - jb);
+    __syncthreads();
+    for (int e = tid; e < PM_TJ * (DD + BB); e += 256) {
+      const int j = e / (DD + BB), c = e - j * (DD + BB);
+      T v = T(0);
+      if (j < nj) {
+        if (c < DD) { if (c < D) v = X[(jb + j) * D + c]; }
+        else if (c - DD < B) v = alpha[(jb + j) * B + (c - DD)];
+      }
+      rows[j * PM_RS + (c < DD ? c : PM_DMAX + (c - DD))] = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int j = 0; j < PM_TJ; ++j) {
+      const Q4* row = reinterpret_cast<const Q4*>(rows + j * PM_RS);
+      T xt[DD], al[BB];
+#pragma unroll
+      for (int g = 0; g < D4; ++g) {
+        const Q4 v = row[g];
+        xt[4 * g] = v.x; xt[4 * g + 1] = v.y; xt[4 * g + 2] = v.z; xt[4 * g + 3] = v.w;
+      }
+#pragma unroll
+      for (int g = 0; g < B4; ++g) {
+        const Q4 v = row[PM_DMAX / 4 + g];
+        al[4 * g] = v.x; al[4 * g + 1] = v.y; al[4 * g + 2] = v.z; al[4 * g + 3] = v.w;
+      }
+#pragma unroll
+      for (int q = 0; q < PM_QPT; ++q) {
+        T sq[DD];
+#pragma unroll
+        for (int d = 0; d < DD; ++d) { const T df = xq[q][d] - xt[d]; sq[d] = df * df; }
+#pragma unroll
+        for (int b = 0; b < BB; ++b) {
+          T d2 = T(0);
+#pragma unroll
+          for (int d = 0; d < DD; ++d) d2 = fma_t(sq[d], wl[b * DD + d], d2);
+          acc[q][b] = fma_t(exp_neg(T(-0.5) * d2), al[b], acc[q][b]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PM_QPT; ++q) {
+    if (qm[q] < M) {
+#pragma unroll
+      for (int b = 0; b < BB; ++b)
+        if (b < B) partial[((long long)blockIdx.y * M + qm[q]) * B + b] = acc[q][b];
+    }
+  }
+}
+
+// mean[m][b] = y_mean[b] + y_std[b] * sf2[b] * sum_s partial[s][m][b]
+template <typename T>
+__global__ void mean_reduce_multi_kernel(const T* __restrict__ partial, int S, long long M, int B, PArr sf2,
+                                         PArr ymean, PArr ystd, T* __restrict__ mean) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * B) return;
+  const int b = (int)(e % B);
+  T s = T(0);
+  for (int k = 0; k < S; ++k) s += partial[(long long)k * M * B + e];
+  mean[e] = T(ymean.v[b]) + T(ystd.v[b]) * (T(sf2.v[b]) * s);
+}
+
+template <typename T>
+using pmm_fn = void (*)(const T*, const T*, long long, int, int, const double*, const T*, long long, long long, T*);
+template <typename T, int D4>
+pmm_fn<T> pmm_pick_b(int b4) {
+  return b4 <= 1 ? predict_mean_multi_kernel<T, D4, 1> : predict_mean_multi_kernel<T, D4, 2>;
+}
+template <typename T>
+pmm_fn<T> pmm_pick(int d4, int b4) {
+  switch (d4) {
+    case 1: return pmm_pick_b<T, 1>(b4);
+    case 2: return pmm_pick_b<T, 2>(b4);
+    case 3: return pmm_pick_b<T, 3>(b4);
+    default: return pmm_pick_b<T, 4>(b4);
+  }
+}
+
 template <typename T>
 __global__ void mean_reduce_kernel(const T* __restrict__ partial, int S, long long M, int P, T sf2, PArr ymean,
                                    PArr ystd, T* __restrict__ mean) {
@@ -488,6 +603,65 @@ extern "C" int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const vo
     GPK_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(mean_reduce_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
                        (const float*)partial, (int)S, (long long)M, P, (float)sf2, ym, ys, (float*)mean);
+  }
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_mean_multi(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
+                                      int B, const double* ls, const double* sf2, const double* y_mean,
+                                      const double* y_std, const void* Xq, int64_t M, void* mean) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && alpha && Xq && mean && ls && sf2 && y_mean && y_std, "predict_mean_multi: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1, "predict_mean_multi: empty input");
+  GPK_REQUIRE(h, D >= 1 && D <= PM_DMAX, "predict_mean_multi: D must be in [1, 16]");
+  GPK_REQUIRE(h, B >= 1 && B <= 8, "predict_mean_multi: B must be in [1, 8]");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "predict_mean_multi: bad dtype");
+  PArr ym{}, ys{}, sf{};
+  double w[8 * PM_DMAX];
+  for (int b = 0; b < B; ++b) {
+    ym.v[b] = y_mean[b]; ys.v[b] = y_std[b]; sf.v[b] = sf2[b];
+    for (int d = 0; d < D; ++d) {
+      GPK_REQUIRE(h, ls[b * D + d] > 0.0, "predict_mean_multi: length-scales must be positive");
+      w[b * D + d] = 1.0 / (ls[b * D + d] * ls[b * D + d]);
+    }
+  }
+  const int64_t nqb = (M + 256 * PM_QPT - 1) / (256 * PM_QPT);
+  int64_t S = (2048 + nqb - 1) / nqb;
+  const int64_t maxS = (N + PM_TJ - 1) / PM_TJ;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  if (S > 65535) S = 65535;
+  int64_t chunk = (N + S - 1) / S;
+  chunk = (chunk + PM_TJ - 1) / PM_TJ * PM_TJ;
+  S = (N + chunk - 1) / chunk;
+  const size_t es = dtype == GPK_F64 ? 8 : 4;
+  const size_t wbytes = 8 * PM_DMAX * sizeof(double);
+  void* ws = nullptr;
+  GPK_TRY(gpk_scratch(h, wbytes + (size_t)S * M * B * es, &ws));
+  double* w_dev = (double*)ws;
+  void* partial = (char*)ws + wbytes;
+  // the weight table is tiny: stage it through the pinned host mirror of the handle
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  memcpy(h->h_small, w, (size_t)B * D * sizeof(double));
+  GPK_CHECK_HIP(h, hipMemcpyAsync(w_dev, h->h_small, (size_t)B * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  dim3 grid((unsigned)nqb, (unsigned)S);
+  const int64_t tot = M * B;
+  const int d4 = (D + 3) / 4, b4 = (B + 3) / 4;
+  if (dtype == GPK_F64) {
+    hipLaunchKernelGGL(pmm_pick<double>(d4, b4), grid, dim3(256), 0, h->stream, (const double*)X,
+                       (const double*)alpha, (long long)N, D, B, (const double*)w_dev, (const double*)Xq,
+                       (long long)M, (long long)chunk, (double*)partial);
+    GPK_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(mean_reduce_multi_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double*)partial, (int)S, (long long)M, B, sf, ym, ys, (double*)mean);
+  } else {
+    hipLaunchKernelGGL(pmm_pick<float>(d4, b4), grid, dim3(256), 0, h->stream, (const float*)X,
+                       (const float*)alpha, (long long)N, D, B, (const double*)w_dev, (const float*)Xq,
+                       (long long)M, (long long)chunk, (float*)partial);
+    GPK_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(mean_reduce_multi_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float*)partial, (int)S, (long long)M, B, sf, ym, ys, (float*)mean);
   }
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;

@@ -76,7 +76,11 @@ class Backend:
 
 
 def get_backend(device_index=None) -> Backend:
+    """Shared per-GPU backend; a `Backend` instance passes through (private handle + stream, used by
+    the concurrent per-model workers of `BatchedARDGP`)."""
     torch = _torch()
+    if isinstance(device_index, Backend):
+        return device_index
     if device_index is None:
         device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
     with _backends_lock:
@@ -322,13 +326,13 @@ class DeviceGP:
         """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units).
 
         method "solve": V = L^-1 K*^T by the blocked triangular solve (the reference's
-        solve_triangular), "inverse": |W k*|^2 with the explicit inverse factor in one fused GEMM
-        launch, "auto": inverse for fp32 (serving), solve for fp64."""
+        solve_triangular; a chain of 2 Np/128 - 1 GEMM launches), "inverse" (= "auto"): |W k*|^2 with the
+        explicit inverse factor W = L^-1, formed once per factorisation, in ONE fused GEMM launch."""
         torch = _torch()
         assert self.factored
         f32 = dtype in ("float32", np.float32, torch.float32)
         if method == "auto":
-            method = "inverse" if f32 else "solve"
+            method = "inverse"
         if method not in ("solve", "inverse"):
             raise ValueError("method must be 'auto', 'solve' or 'inverse'")
         tdt = torch.float32 if f32 else torch.float64

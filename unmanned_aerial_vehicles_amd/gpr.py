@@ -42,7 +42,7 @@ def _rng_from(random_state):
 class GaussianProcessRegressor:
     def __init__(self, kernel=None, *, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
                  normalize_y=False, copy_X_train=True, n_targets=None, random_state=None, device=None,
-                 predict_dtype="float64"):
+                 predict_dtype="float64", var_method="auto"):
         self.kernel = kernel
         self.alpha = alpha
         self.optimizer = optimizer
@@ -53,6 +53,7 @@ class GaussianProcessRegressor:
         self.random_state = random_state
         self.device = device
         self.predict_dtype = predict_dtype
+        self.var_method = var_method      # 'auto' | 'inverse' | 'solve' (see DeviceGP.predict_var_dev)
         self._dev = None
 
     # ------------------------------------------------------------------ fit
@@ -193,18 +194,20 @@ class GaussianProcessRegressor:
             return mean
         self._ensure_device()
         dev = self._dev
-        mean = dev.predict_mean_dev(X, self._y_train_mean, self._y_train_std, self.predict_dtype)
-        mean = mean.double().cpu().numpy()
-        if mean.shape[1] == 1:
-            mean = mean[:, 0]
+        import torch
+        q = dev.be.upload(X, torch.float32 if self.predict_dtype == "float32" else torch.float64)
+        mean_d = dev.predict_mean_dev(q, self._y_train_mean, self._y_train_std, self.predict_dtype).double()
         if not return_std:
-            return mean
+            mean = mean_d.cpu().numpy()
+            return mean[:, 0] if mean.shape[1] == 1 else mean
         comp = self.kernel_.components()
         kss = comp.sf2 + (comp.noise or 0.0)        # kernel_.diag(X): RBF diag + WhiteKernel level
-        var = dev.predict_var_dev(X, kss, 0.0, self.predict_dtype).cpu().numpy()   # clipped at 0 (_gpr.py:479-485)
+        var_d = dev.predict_var_dev(q, kss, 0.0, self.predict_dtype, self.var_method)   # clipped at 0 (_gpr.py:479-485)
+        both = torch.cat([mean_d, var_d[:, None]], dim=1).cpu().numpy()              # one device->host copy
+        mean, var = both[:, :-1], both[:, -1]
         var = np.outer(var, self._y_train_std ** 2)
-        if var.shape[1] == 1:
-            var = var[:, 0]
+        if mean.shape[1] == 1:
+            mean, var = mean[:, 0], var[:, 0]
         return mean, np.sqrt(var)
 
     # ------------------------------------------------------------------ host views / persistence
