@@ -94,6 +94,11 @@ int gpk_factor_to_f32(gpk_handle h, const double* L, int64_t Np, int64_t ldl, co
 int gpk_potrs(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
               const double* Y, int64_t N, int P, double* alpha);
 
+/* K3 through the explicit inverse factor W = L^-1 (gpk_trtri): alpha = W^T (W Y), two GEMM launches
+ * that each stream W once, instead of the 4 Np/128 - 2 launches of the recursive solve.              */
+int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const double* Y, int64_t N,
+                  int P, double* alpha);
+
 /* ---- K5 building blocks: B <- L^-1 B, and column sums of squares ---------------------
  * B: dev (Np x ldb) with Mp = multiple of 128 columns in use.  dtype selects fp32/fp64
  * (L, winv and B must all have that dtype).
@@ -164,6 +169,8 @@ int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t ldl, const d
  * Replaces: cho_solve((L, True), eye(N)) at sklearn/gaussian_process/_gpr.py:627-629.           */
 int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
               double* Kinv, int64_t ldk, double* work);
+/* The second half of gpk_potri when W = L^-1 is already at hand: Kinv (lower tiles) = W^T W.       */
+int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, double* Kinv, int64_t ldk);
 /* grad[d] (d < D) = 0.5 * sum_ij Q_ij K_ij ((x_id - x_jd)/ls_d)^2, grad[D] = 0.5 * noise * tr(Q),
  * Q = alpha alpha^T - P * Kinv, K_ij = sf2 exp(-0.5 d2_ij) recomputed on the fly (the
  * N x N x D tensor sklearn builds at kernels.py:1576-1579 is never materialised).

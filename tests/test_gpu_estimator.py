@@ -298,3 +298,39 @@ def test_batched_per_axis_ard_gps(csv_data, ka):
     bg2._fused = None
     ref1 = bg2.models[1].predict(Xq)
     assert relerr(bg2.predict(Xq)[:, 1], ref1) < 1e-12
+
+
+def test_offline_cli_round_trip(csv_data, ka, tmp_path):
+    """train_offline CLI -> pickle + latest symlink -> evaluate_offline CLI -> metrics CSV."""
+    from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP, evaluate_offline, train_offline
+    from unmanned_aerial_vehicles_amd.data import save_dataset_csv
+    d = tmp_path / "data"
+    save_dataset_csv(str(d / "gp_mpc_data_a.csv"), csv_data["X10"][:300], csv_data["Y6"][:300])
+    save_dataset_csv(str(d / "gp_mpc_data_b.csv"), csv_data["X10"][300:450], csv_data["Y6"][300:450])
+    np.random.seed(0)
+    assert train_offline.main(["--data_dir", str(d), "--output_dir", str(tmp_path / "models"),
+                               "--model_name", "unit"]) == 0
+    latest = tmp_path / "models" / "gp_model_latest.pkl"
+    assert latest.is_symlink() and (tmp_path / "models" / "unit.pkl").exists()
+    gp = SimpleQuadrotorGP()
+    assert gp.load_model(str(latest))
+    assert gp.gp_model.X_train_.shape == (450, 10)
+    assert evaluate_offline.main(["--model-path", str(latest), "--data-path", str(d / "gp_mpc_data_b.csv")]) == 0
+    lines = open(d / "gp_mpc_data_b_metrics.csv").read().strip().splitlines()
+    assert lines[0] == "component,mse_nom,mse_gp,rmse_nom,rmse_gp,improvement_%,r2_nom,r2_gp,frac_better"
+    assert [ln.split(",")[0] for ln in lines[1:]] == ["dx", "dy", "dz", "dvx", "dvy", "dvz"]
+    assert train_offline.main(["--data_dir", str(tmp_path / "nothing"), "--output_dir", str(tmp_path)]) == 1
+    # confidence-gated horizon (mpc_direct_rates.py:317-355): loop of single predicts vs one batched call
+    ls, noise = np.exp(ka["ka3_theta"])
+    gp.gp_model = _gpr(ls, noise).fit(csv_data["X10"], csv_data["Y6"])
+    Xg, Ug = ka["ka3_hor_X"], ka["ka3_hor_U"]
+    singles = [gp.predict_residual(Xg[:, k], Ug[:, k]) for k in range(25)]
+    unc = np.array([np.sqrt(np.sum(v)) for _, v in singles])
+    thr = float(np.median(unc)) * (1 + 1e-9)
+    gated = gp.predict_horizon_gated(Xg, Ug, thr)
+    kept = 0
+    for k, (m, v) in enumerate(singles):
+        ref = m if unc[k] < thr else np.zeros(6)
+        kept += int(unc[k] < thr)
+        assert np.allclose(gated[k], ref, rtol=1e-9, atol=1e-13)
+    assert 0 < kept < 25

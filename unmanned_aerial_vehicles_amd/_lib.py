@@ -34,6 +34,8 @@ SIGNATURES = {
     "gpk_leaf_inverses": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gpk_factor_to_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "gpk_potrs": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp]),
+    "gpk_potrs_inv": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _int, _vp]),
+    "gpk_wtw": (_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "gpk_trsm_lower_left": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _vp, _i64, _i64]),
     "gpk_colsumsq": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp]),
     "gpk_predict_mean": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _vp]),

@@ -411,6 +411,17 @@ extern "C" int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_
   return GPK_OK;
 }
 
+extern "C" int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, double* Kinv, int64_t ldk) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, W && Kinv, "wtw: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldw >= Np && ldk >= Np, "wtw: Np must be a multiple of 128");
+  // Kinv (lower tiles) = W^T W: C[i][j] = sum_{k >= i} W[k][i] W[k][j]
+  GemmArgs g = gemm_args(W, ldw, 1, W, ldw, 1, Kinv, ldk, (int)Np, (int)Np, (int)Np, 1.0, 0.0);
+  g.lower_only = 1;
+  g.kb_row = NB;
+  return gpk_gemm(h, GPK_F64, g);
+}
+
 extern "C" int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* Kinv,
                          int64_t ldk, double* work) {
   if (!h) return GPK_BAD_ARG;
@@ -420,9 +431,32 @@ extern "C" int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl,
   // Kinv doubles as the recursion scratch T before it is written
   double* W = work;
   GPK_TRY(trtri_rec(h, L, ldl, Np, winv, W, Np, Kinv, ldk));
-  // Kinv (lower tiles) = W^T W: C[i][j] = sum_{k >= i} W[k][i] W[k][j]
-  GemmArgs g = gemm_args(W, Np, 1, W, Np, 1, Kinv, ldk, (int)Np, (int)Np, (int)Np, 1.0, 0.0);
-  g.lower_only = 1;
-  g.kb_row = NB;
-  return gpk_gemm(h, GPK_F64, g);
+  return gpk_wtw(h, W, Np, Np, Kinv, ldk);
+}
+
+extern "C" int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const double* Y, int64_t N,
+                             int P, double* alpha) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, W && Y && alpha, "potrs_inv: null pointer");
+  GPK_REQUIRE(h, Np % NB == 0 && N >= 1 && N <= Np && ldw >= Np, "potrs_inv: bad sizes");
+  GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P, "potrs_inv: P must be in [1, 16]");
+  void* ws = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)2 * Np * NB * sizeof(double), &ws));
+  double* Yp = (double*)ws;
+  double* Z = Yp + Np * NB;
+  const long long tot = Np * NB;
+  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, Y,
+                     (long long)N, P, Yp, (long long)Np);
+  GPK_LAUNCH_CHECK(h);
+  // Z = W Yp   (W lower: k < row-tile end), then Yp = W^T Z   (k >= row-tile start): two launches
+  GemmArgs g1 = gemm_args(W, ldw, 0, Yp, NB, 1, Z, NB, (int)Np, NB, (int)Np, 1.0, 0.0);
+  g1.ke0 = NB; g1.ke_row = NB; g1.heavy_first = 1;
+  GPK_TRY(gpk_gemm(h, GPK_F64, g1));
+  GemmArgs g2 = gemm_args(W, ldw, 1, Z, NB, 1, Yp, NB, (int)Np, NB, (int)Np, 1.0, 0.0);
+  g2.kb_row = NB;
+  GPK_TRY(gpk_gemm(h, GPK_F64, g2));
+  hipLaunchKernelGGL(unpack_rhs_kernel, dim3((unsigned)((N * P + 255) / 256)), dim3(256), 0, h->stream,
+                     (const double*)Yp, (long long)N, P, alpha);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
 }

@@ -327,6 +327,8 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_kernel(KParams p) {
     } else {
       R = st / p.nsc;
       S = st - R * p.nsc;
+      S = (S + R) % p.nsc;   // rotate per super-row: with nsc % 8 == 0 an XCD would otherwise always get the
+                             // same super-columns (unbalanced when the k-range depends on the column)
     }
     tm = p.sr * R + (slot & (p.sr - 1));
     tn = (64 / p.sr) * S + slot / p.sr;

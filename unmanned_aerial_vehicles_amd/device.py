@@ -104,6 +104,9 @@ class DeviceGP:
     # largest scratch (bytes) used for one variance panel  V = L^-1 K*^T
     VAR_PANEL_BYTES = 6 << 30
     VAR_PANEL_MAX = 16384
+    # up to this padded size the inverse factor W = L^-1 is formed right away (cheap), so that alpha and
+    # every later variance / gradient call are single launches
+    INVERSE_EAGER_NP = 32768
 
     def __init__(self, X, Yn, backend: Backend | None = None):
         torch = _torch()
@@ -130,7 +133,6 @@ class DeviceGP:
         self._f32 = None    # dict of fp32 copies: X, alpha [, L, winv]
         self._Winv = {}     # explicit inverse factor L^-1: {'f64': tensor} and/or {'f32': tensor}
         self._Kinv = None
-        self._W = None
 
     # ---- fit-side -------------------------------------------------------------------------
     def _ensure_K(self):
@@ -180,15 +182,28 @@ class DeviceGP:
         self._f32 = None
         self._Winv = {}
 
-    def solve_alpha(self):
-        """K3: alpha = L^-T L^-1 Yn."""
+    def solve_alpha(self, method="auto"):
+        """K3: alpha = L^-T L^-1 Yn.  "chain": recursive blocked solves with L; "inverse": W^T (W Yn)
+        with the explicit inverse factor (two launches); "auto": inverse if W is already at hand or
+        cheap to form (Np <= INVERSE_EAGER_NP), else chain."""
         assert self.factored
         be = self.be
-        with be.lock:
-            be.bind_stream()
-            be.check(be.lib.gpk_potrs(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self.Yn), self.N,
-                                      self.P, _p(self.alpha)))
-        self._f32 = None
+        if method == "auto":
+            method = "inverse" if ("f64" in self._Winv or self.Np <= self.INVERSE_EAGER_NP) else "chain"
+        if method == "inverse":
+            W = self.inverse_factor(False)
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_potrs_inv(be.h, _p(W), self.Np, self.Np, _p(self.Yn), self.N, self.P,
+                                              _p(self.alpha)))
+        else:
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_potrs(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self.Yn), self.N,
+                                          self.P, _p(self.alpha)))
+        self._f32 = None if self._f32 is None else {k: v for k, v in self._f32.items() if k not in ("alpha",)}
+        if self._f32 is not None and "X" not in self._f32:
+            self._f32 = None
 
     def set_alpha(self, alpha):
         self.alpha.copy_(self.be.upload(np.asarray(alpha, dtype=np.float64).reshape(self.N, self.P)))
@@ -212,13 +227,12 @@ class DeviceGP:
             raise ValueError("analytic LML gradients support D <= 16")
         if self._Kinv is None:
             self._Kinv = self.be.empty((self.Np, self.Np), torch.float64)
-            self._W = self.be.empty((self.Np, self.Np), torch.float64)
+        W = self.inverse_factor(False)
         be = self.be
         g = np.zeros(self.D + 2)
         with be.lock:
             be.bind_stream()
-            be.check(be.lib.gpk_potri(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self._Kinv), self.Np,
-                                      _p(self._W)))
+            be.check(be.lib.gpk_wtw(be.h, _p(W), self.Np, self.Np, _p(self._Kinv), self.Np))
             be.check(be.lib.gpk_lml_grad(be.h, _p(self.X), self.N, self.D, self.ls.ctypes.data_as(_lib._dp),
                                          self.sf2, float(noise), _p(self.alpha), self.P, _p(self._Kinv), self.Np,
                                          g.ctypes.data_as(_lib._dp)))
@@ -226,7 +240,6 @@ class DeviceGP:
 
     def release_grad_buffers(self):
         self._Kinv = None
-        self._W = None
 
     # ---- host views ------------------------------------------------------------------------
     def L_host(self):
@@ -240,7 +253,11 @@ class DeviceGP:
         """fp32 copies of X and alpha (enough for the fused mean)."""
         torch = _torch()
         if self._f32 is None:
-            self._f32 = {"X": self.X.to(torch.float32), "alpha": self.alpha.to(torch.float32)}
+            self._f32 = {}
+        if "X" not in self._f32:
+            self._f32["X"] = self.X.to(torch.float32)
+        if "alpha" not in self._f32:
+            self._f32["alpha"] = self.alpha.to(torch.float32)
         return self._f32
 
     def _f32_factor(self):

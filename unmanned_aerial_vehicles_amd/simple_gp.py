@@ -169,6 +169,23 @@ class SimpleQuadrotorGP:
                 D[:, 3:6, :] = acc.transpose(0, 2, 1)
         return D[0] if single else D
 
+    def predict_horizon_gated(self, X_guess, U_guess, confidence_threshold, n_states=6):
+        """Batched counterpart of `_get_gp_predictions_for_horizon`
+        (src/px4/mpc_direct_rates.py:317-355): one mean+variance call for the whole horizon; stage k keeps
+        the GP residual only if sqrt(sum_p var_kp) < confidence_threshold, otherwise zeros (nominal
+        dynamics).  Returns (N, n_states)."""
+        X_guess = np.asarray(X_guess, dtype=float)
+        U_guess = np.asarray(U_guess, dtype=float)
+        N = U_guess.shape[1]
+        out = np.zeros((N, n_states))
+        if not self.is_trained:
+            return out
+        rows = np.concatenate([X_guess[:6, :N], U_guess[:4, :N]], axis=0).T
+        mean, var = self.predict_residual_batch(rows, return_var=True)
+        keep = np.sqrt(np.sum(var, axis=1)) < confidence_threshold
+        out[keep] = mean[keep, :n_states]
+        return out
+
     def get_uncertainty(self, state, control):
         _, variance = self.predict_residual(state, control)
         return np.mean(np.sqrt(variance))
