@@ -273,7 +273,7 @@ def main():
             "roofline": roof,
             "fit": fit,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -258,6 +258,16 @@ def test_full_size_properties():
     mean = dev.predict_mean_dev(X[idx], np.zeros(3), np.ones(3), "float64").cpu().numpy()
     alpha = dev.alpha_host()
     assert np.max(np.abs(mean - (Yn[idx] - s * alpha[idx]))) < 1e-9
+    # fp32 serving path (inverse factor, fused GEMM) against the fp64 solve path at the same size
+    Xq = np.random.default_rng(1).standard_normal((512, 9))
+    v64 = dev.predict_var_dev(Xq, 1.1, 0.0, "float64", "solve").cpu().numpy()
+    v64i = dev.predict_var_dev(Xq, 1.1, 0.0, "float64", "inverse").cpu().numpy()
+    v32 = dev.predict_var_dev(Xq, 1.1, 0.0, "float32", "inverse").cpu().numpy()
+    assert np.max(np.abs(v64i - v64)) < 1e-10
+    assert np.max(np.abs(np.sqrt(v32) - np.sqrt(v64)) / np.sqrt(v64)) < 1e-3      # stated fp32 tolerance on std
+    m64 = dev.predict_mean_dev(Xq, np.zeros(3), np.ones(3), "float64").cpu().numpy()
+    m32 = dev.predict_mean_dev(Xq, np.zeros(3), np.ones(3), "float32").double().cpu().numpy()
+    assert np.max(np.abs(m32 - m64)) < 1e-4 * np.max(np.abs(m64))
     rows = [5, 4097, 9000, N - 1]
     Lr = dev.K[rows].cpu().numpy()
     for a, i in enumerate(rows):
