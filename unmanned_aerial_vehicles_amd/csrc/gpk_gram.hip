@@ -192,6 +192,101 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ X, 
   }
 }
 
+// ---- K1, strip form (D <= 16): one workgroup owns tile row ti and a strip of up to GS consecutive
+// column tiles.  The row block's X is staged once; the X rows of the next column tile are fetched into
+// registers while the current tile is computed and stored, so the global-load latency of each tile is
+// hidden, and the 512-byte row segments of neighbouring tiles are written back to back by one workgroup.
+constexpr int GS = 8;
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void gram_strip_kernel(const T* __restrict__ X, long long N, int D, LsArr ls,
+                                                         T sf2, T diag_add, T* __restrict__ K, long long ldk) {
+  __shared__ __attribute__((aligned(16))) T xi[DCH * TS];
+  __shared__ __attribute__((aligned(16))) T xj[DCH * TS];
+  __shared__ __attribute__((aligned(16))) T tb[TS * (TS + 1)];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  // strip id -> (ti, g): tile row r has floor(r / GS) + 1 strips; rows [GS q, GS q + GS) hold GS (q + 1) strips
+  const long long id = blockIdx.x;
+  long long q = (long long)((__builtin_sqrt(1.0 + 8.0 * (double)id / GS) - 1.0) * 0.5);   // (GS/2) q (q+1) <= id
+  while ((GS / 2) * (q + 1) * (q + 2) <= id) ++q;
+  while ((GS / 2) * q * (q + 1) > id) --q;
+  const long long rem_id = id - (GS / 2) * q * (q + 1);
+  const long long ti = GS * q + rem_id / (q + 1);
+  const long long g = rem_id % (q + 1);
+  const long long i0 = ti * TS;
+  const long long tj0 = g * GS, tj1 = min(ti, tj0 + GS - 1);
+
+  stage_x<T>(X, N, D, i0, 0, D, ls, xi, tid);
+  stage_x<T>(X, N, D, tj0 * TS, 0, D, ls, xj, tid);
+  // per-thread prefetch registers for the next column tile: element e = tid + 256 p of the (64 x D) block
+  constexpr int NPF = (TS * DCH + 255) / 256;   // 4
+  T pf[NPF];
+  __syncthreads();
+  for (long long tj = tj0; tj <= tj1; ++tj) {
+    const long long j0 = tj * TS;
+    const bool more = tj < tj1;
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < NPF; ++p) {
+        const int e = tid + 256 * p;
+        const int i = e / D, d = e - i * D;
+        const long long gi = j0 + TS + i;
+        pf[p] = (e < TS * D && gi < N) ? X[gi * D + d] / T(ls.v[d]) : T(0);
+      }
+    }
+    T d2[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d2[r][c] = T(0);
+    accum_d2<T>(xi, xj, D, ty, tx, d2);
+    T v[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long gi = i0 + 4 * ty + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long long gj = j0 + colof<T>(tx, c);
+        T val = sf2 * exp_neg(T(-0.5) * d2[r][c]);
+        if (gi == gj) val = sf2 + diag_add;
+        if (gi >= N || gj >= N) val = (gi == gj) ? T(1) : T(0);
+        v[r][c] = val;
+      }
+      store_row4(K + gi * ldk + j0, tx, v[r], NT);
+    }
+    if (ti != tj) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tb[(4 * ty + r) * (TS + 1) + colof<T>(tx, c)] = v[r][c];
+    }
+    __syncthreads();          // tb complete; every thread is done reading xj
+    if (ti != tj) {
+      constexpr int VEC = Vec16<T>::N;
+      constexpr int LPR = TS / VEC;
+      constexpr int RPG = TS / (256 / LPR);
+      const int lp = tid % LPR, gg = tid / LPR;
+#pragma unroll
+      for (int rr = 0; rr < RPG; ++rr) {
+        const int jj = gg * RPG + rr;
+        T w[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[e] = tb[(VEC * lp + e) * (TS + 1) + jj];
+        T* dst = K + (j0 + jj) * ldk + i0 + VEC * lp;
+        if constexpr (VEC == 2) st16(dst, w[0], w[1], NT);
+        else st16(dst, w[0], w[1], w[2], w[3], NT);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < NPF; ++p) {
+        const int e = tid + 256 * p;
+        if (e < TS * D) { const int i = e / D, d = e - i * D; xj[d * TS + i] = pf[p]; }
+      }
+    }
+    __syncthreads();          // xj holds the next tile; tb may be overwritten
+  }
+}
+
 // ---- K*^T block: B[j][m] = sf2 exp(-0.5 |x_j - xq_m|^2), zero in the padding -------------------
 template <typename T>
 __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, long long N,
@@ -526,10 +621,22 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
   bool stream_nt = Np >= 16384;   // streaming stores once K exceeds the caches
   if (const char* e = getenv("GPK_GRAM_NT")) stream_nt = (e[0] == '1');   // tuning override
   GPK_REQUIRE(h, ((uintptr_t)K % 16) == 0, "gram: K must be 16-byte aligned");
-  const dim3 grid((unsigned)tiles), block(256);
-#define GPK_GRAM_LAUNCH(T, NT)                                                                          \
-  hipLaunchKernelGGL((gram_sym_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
-                     (T)sf2, (T)diag_add, (T*)K, (long long)ldk)
+  const dim3 block(256);
+  // strip kernel for D <= 16 (one chunk of features); the tile-per-workgroup kernel otherwise
+  bool strip = D <= DCH;
+  if (const char* e = getenv("GPK_GRAM_STRIP")) strip = strip && (e[0] == '1');
+  long long nstrips = 0;
+  for (long long r = 0; r < nt; ++r) nstrips += r / GS + 1;
+  const dim3 grid((unsigned)(strip ? nstrips : tiles));
+#define GPK_GRAM_LAUNCH(T, NT)                                                                              \
+  do {                                                                                                      \
+    if (strip)                                                                                              \
+      hipLaunchKernelGGL((gram_strip_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
+                         (T)sf2, (T)diag_add, (T*)K, (long long)ldk);                                       \
+    else                                                                                                    \
+      hipLaunchKernelGGL((gram_sym_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l,  \
+                         (T)sf2, (T)diag_add, (T*)K, (long long)ldk);                                       \
+  } while (0)
   if (dtype == GPK_F64) { if (stream_nt) GPK_GRAM_LAUNCH(double, true); else GPK_GRAM_LAUNCH(double, false); }
   else { if (stream_nt) GPK_GRAM_LAUNCH(float, true); else GPK_GRAM_LAUNCH(float, false); }
 #undef GPK_GRAM_LAUNCH
