@@ -297,6 +297,8 @@ def test_batched_per_axis_ard_gps(csv_data, ka):
         assert lml.shape == (3,) and grad.shape == (3, 10)
         assert abs(lml[0] - ka["ka6b_lml"]) < 1e-10 * abs(lml[0])
         assert relerr(grad[0], ka["ka6b_grad"]) < 1e-8
+    bg3 = pickle.loads(pickle.dumps(bg))                 # models carry a private backend: must still pickle
+    assert relerr(bg3.predict(Xq), mean) < 1e-12
     # fp32 fused predict
     bg.predict_dtype = "float32"
     bg._fused = None

@@ -34,6 +34,11 @@ class BatchedARDGP:
         self._workers = []
         self._fused = None
 
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_workers"], st["_fused"] = [], None          # handles, streams and device tensors are rebuilt lazily
+        return st
+
     # ------------------------------------------------------------------ workers
     def _backend(self, b):
         import torch

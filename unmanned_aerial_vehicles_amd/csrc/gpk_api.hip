@@ -25,6 +25,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   h->stream = h->own_stream;
   if (const char* e = getenv("GPK_GEMM_WM_F64")) h->gemm_wm_f64 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
+  if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
   *out = h;
   return GPK_OK;
 }
@@ -102,14 +103,15 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   GPK_TRY(gpk_cross_gram_t(h, dtype, Xq, M, X, N, D, ls, sf2, work, Np));
   // one launch: V = W Kq^T tile by tile (W lower: k < row-tile end), V never stored, only the per-tile
   // column sums of squares: partial[tile_row][m]
-  const int ntm = (int)(Np / GPK_TILE);
-  void* partial = nullptr;
-  GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
-  GemmArgs g = gemm_args(W, ldw, 0, work, Np, 0, partial, Mp, (int)Np, (int)Mp, (int)Np, 1.0, 0.0);
+  GemmArgs g = gemm_args(W, ldw, 0, work, Np, 0, nullptr, Mp, (int)Np, (int)Mp, (int)Np, 1.0, 0.0);
   g.ke0 = GPK_TILE;
   g.ke_row = GPK_TILE;
   g.epilogue = 1;
   g.heavy_first = 1;   // row tile tm costs (tm + 1) k-blocks: start the long ones first
+  const int ntm = (int)(Np / gpk_gemm_tile(h, g));       // one partial row per tile row of the launch
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
+  g.C = partial;
   GPK_TRY(gpk_gemm(h, dtype, g));
   GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
   return gpk_var_finalize(h, var, M, kss, floor_, var);

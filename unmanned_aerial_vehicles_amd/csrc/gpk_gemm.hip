@@ -1,15 +1,15 @@
 // Dense tile GEMM on the gfx950 matrix cores: the workhorse behind the blocked Cholesky
-// (syrk / trsm / gemm updates), the triangular solves and K^-1.
+// (syrk / trsm / gemm updates), the triangular solves, K^-1 and the posterior variance.
 //
-//   C[m x n] = alpha * opA(A) * opB(B)^T + beta * C        (whole 128 x 128 tiles)
+//   C[m x n] = alpha * opA(A) * opB(B)^T + beta * C        (whole TS x TS tiles, TS = 128 or 64)
 //
-// fp64 uses v_mfma_f64_16x16x4_f64, fp32 uses v_mfma_f32_32x32x2_f32 (exact f32).  One
-// workgroup = 4 waves (2 x 2), each wave owns a 64 x 64 sub-tile; the k-loop stages
-// 128 rows x 128 bytes of each operand through LDS with register prefetch of the next
-// k-tile (one barrier per k-tile, two LDS buffers).  Operands may be stored k-contiguous
-// or k-strided; the LDS image keeps the global orientation and only the fragment reads
-// differ.  blockIdx is remapped so that each XCD (private L2) sweeps a compact group of
-// tiles that share operand panels.
+// fp64 uses v_mfma_f64_16x16x4_f64, fp32 uses v_mfma_f32_32x32x2_f32 (exact f32).  A workgroup is
+// WM x 2 waves; each wave owns a (TS/WM) x (TS/2) sub-tile.  The k-loop stages TS rows x 128 bytes of
+// each operand through LDS with a register-staged software pipeline (one barrier per k-tile, two LDS
+// buffers).  Operands may be stored k-contiguous or k-strided; the LDS image keeps the global
+// orientation and only the fragment reads differ.  Large grids are walked in 64-tile super-tiles
+// interleaved over the 8 XCDs; small grids (which cannot fill 256 CUs with 128 x 128 tiles) use
+// 64 x 64 tiles for 4x the parallelism.
 #include "gpk_internal.h"
 
 namespace {
@@ -17,19 +17,11 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128;
 constexpr int LDS_N_STRIDE = 144;    // bytes per row of a k-contiguous tile (128 + 16 pad)
-constexpr int LDS_OP_BYTES = 128 * LDS_N_STRIDE;  // 18432, also >= k-strided image
 
 template <typename T> struct Cfg;
-template <> struct Cfg<double> {
-  static constexpr int BK = 16;           // k elements per tile
-  static constexpr int T_STRIDE = 132;    // elements per row of a k-strided tile
-};
-template <> struct Cfg<float> {
-  static constexpr int BK = 32;
-  static constexpr int T_STRIDE = 132;
-};
+template <> struct Cfg<double> { static constexpr int BK = 16; };   // k elements per k-tile (128 bytes)
+template <> struct Cfg<float> { static constexpr int BK = 32; };
 
 struct KParams {
   const char* A;
@@ -38,7 +30,7 @@ struct KParams {
   long long lda, ldb, ldc;  // in elements
   int m, n, k;
   double alpha, beta;
-  int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;
+  int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;   // k-range coefficients per 128-row tile index
   int ntm, ntn;
   int heavy_first;            // reverse the tile-row order (k-range grows with the row: longest tiles first)
   int direct, nst, nsc, sr;   // tile mapping: direct grid, or super-tiles (count, per super-row, rows)
@@ -46,15 +38,15 @@ struct KParams {
 
 typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
 
-// ---- global -> registers: 4 x 16 B per thread per operand -------------------------------
-// NT = threads per workgroup (256 or 512); an operand k-tile is 1024 chunks of 16 bytes, NP per thread
-template <typename T, bool TR, int NT>
+// ---- global -> registers -> LDS -------------------------------------------------------------------
+// An operand k-tile is TS rows x 128 bytes = TS * 8 chunks of 16 bytes, NP = TS * 8 / NT per thread.
+template <typename T, bool TR, int NT, int TS>
 __device__ __forceinline__ void load_tile(const T* __restrict__ base, long long ld, int row0, int k0,
-                                          int tid, V16 (&r)[1024 / NT]) {
+                                          int tid, V16 (&r)[TS * 8 / NT]) {
   constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
-  constexpr int NP = 1024 / NT;
+  constexpr int NP = TS * 8 / NT;
   if constexpr (!TR) {
-    // stored (rows x k): thread -> chunk c of row (tid>>3) + (NT/8) p
+    // stored (rows x k): thread -> chunk c of row (tid >> 3) + (NT / 8) p
     const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -62,8 +54,8 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, long long 
       r[p] = *reinterpret_cast<const V16*>(g);
     }
   } else {
-    // stored (k x rows): BK k-rows of 128 elements
-    constexpr int CPR = 128 / EPC;       // chunks per k-row: 64 (f64) / 32 (f32)
+    // stored (k x rows): BK k-rows of TS elements
+    constexpr int CPR = TS / EPC;        // chunks per k-row
     constexpr int RPP = NT / CPR;        // k-rows per pass
     const int c = tid % CPR, kr = tid / CPR;
 #pragma unroll
@@ -74,19 +66,19 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ base, long long 
   }
 }
 
-template <typename T, bool TR, int NT>
-__device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[1024 / NT]) {
+template <typename T, bool TR, int NT, int TS>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[TS * 8 / NT]) {
   constexpr int EPC = 16 / sizeof(T);
-  constexpr int NP = 1024 / NT;
+  constexpr int NP = TS * 8 / NT;
   if constexpr (!TR) {
     const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
     for (int p = 0; p < NP; ++p)
       *reinterpret_cast<V16*>(lds + (rr + (NT / 8) * p) * LDS_N_STRIDE + c * 16) = r[p];
   } else {
-    constexpr int CPR = 128 / EPC;
+    constexpr int CPR = TS / EPC;
     constexpr int RPP = NT / CPR;
-    constexpr int RS = Cfg<T>::T_STRIDE * sizeof(T);
+    constexpr int RS = (TS + 4) * sizeof(T);   // padded k-row: conflict-free fragment reads
     const int c = tid % CPR, kr = tid / CPR;
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -94,36 +86,36 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[10
   }
 }
 
-// ---- fp64: AB x 4 blocks of 16x16x4 per wave (wave tile 16 AB rows x 64 columns) ------------------
-template <bool TA, bool TB, int AB>
-__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane,
-                                             d4 (&acc)[AB][4]) {
+// ---- fp64: AB x NB blocks of 16x16x4 per wave.  Within a k-tile the k index is permuted so that a lane's
+// four k values (4 kq .. 4 kq + 3) are contiguous: two ds_read_b128 per block row for k-contiguous images.
+template <bool TA, bool TB, int AB, int NB, int TS>
+__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int row_w, int col_w, int lane,
+                                             d4 (&acc)[AB][NB]) {
   const int r = lane & 15, kq = lane >> 4;
-  constexpr int RS = Cfg<double>::T_STRIDE * 8;
-  constexpr int RW = 16 * AB;
+  constexpr int RS = (TS + 4) * 8;
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
-    double af[AB][2], bf[4][2];
+    double af[AB][2], bf[NB][2];
 #pragma unroll
     for (int a = 0; a < AB; ++a) {
       if constexpr (!TA) {
-        const double2 v = *reinterpret_cast<const double2*>(la + (wm * RW + 16 * a + r) * LDS_N_STRIDE +
+        const double2 v = *reinterpret_cast<const double2*>(la + (row_w + 16 * a + r) * LDS_N_STRIDE +
                                                             (4 * kq + 2 * hh) * 8);
         af[a][0] = v.x; af[a][1] = v.y;
       } else {
-        af[a][0] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh) * RS + (wm * RW + 16 * a + r) * 8);
-        af[a][1] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh + 1) * RS + (wm * RW + 16 * a + r) * 8);
+        af[a][0] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh) * RS + (row_w + 16 * a + r) * 8);
+        af[a][1] = *reinterpret_cast<const double*>(la + (4 * kq + 2 * hh + 1) * RS + (row_w + 16 * a + r) * 8);
       }
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NB; ++b) {
       if constexpr (!TB) {
-        const double2 v = *reinterpret_cast<const double2*>(lb + (wn * 64 + 16 * b + r) * LDS_N_STRIDE +
+        const double2 v = *reinterpret_cast<const double2*>(lb + (col_w + 16 * b + r) * LDS_N_STRIDE +
                                                             (4 * kq + 2 * hh) * 8);
         bf[b][0] = v.x; bf[b][1] = v.y;
       } else {
-        bf[b][0] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh) * RS + (wn * 64 + 16 * b + r) * 8);
-        bf[b][1] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh + 1) * RS + (wn * 64 + 16 * b + r) * 8);
+        bf[b][0] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh) * RS + (col_w + 16 * b + r) * 8);
+        bf[b][1] = *reinterpret_cast<const double*>(lb + (4 * kq + 2 * hh + 1) * RS + (col_w + 16 * b + r) * 8);
       }
     }
 #pragma unroll
@@ -131,43 +123,43 @@ __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int
 #pragma unroll
       for (int a = 0; a < AB; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
   }
 }
 
-// ---- fp32: AB x 2 blocks of 32x32x2 per wave (wave tile 32 AB rows x 64 columns) --------------------
-template <bool TA, bool TB, int AB>
-__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane,
-                                             f16v (&acc)[AB][2]) {
+// ---- fp32: AB x NB blocks of 32x32x2 per wave; a lane's sixteen k values (16 kq .. 16 kq + 15) are
+// contiguous: four ds_read_b128 per block row.
+template <bool TA, bool TB, int AB, int NB, int TS>
+__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int row_w, int col_w, int lane,
+                                             f16v (&acc)[AB][NB]) {
   const int r = lane & 31, kq = lane >> 5;
-  constexpr int RS = Cfg<float>::T_STRIDE * 4;
-  constexpr int RW = 32 * AB;
+  constexpr int RS = (TS + 4) * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // 4 groups of 4 k-steps
-    float af[AB][4], bf[2][4];
+    float af[AB][4], bf[NB][4];
 #pragma unroll
     for (int a = 0; a < AB; ++a) {
       if constexpr (!TA) {
-        const float4 v = *reinterpret_cast<const float4*>(la + (wm * RW + 32 * a + r) * LDS_N_STRIDE +
+        const float4 v = *reinterpret_cast<const float4*>(la + (row_w + 32 * a + r) * LDS_N_STRIDE +
                                                           (16 * kq + 4 * q) * 4);
         af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          af[a][t] = *reinterpret_cast<const float*>(la + (16 * kq + 4 * q + t) * RS + (wm * RW + 32 * a + r) * 4);
+          af[a][t] = *reinterpret_cast<const float*>(la + (16 * kq + 4 * q + t) * RS + (row_w + 32 * a + r) * 4);
       }
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB; ++b) {
       if constexpr (!TB) {
-        const float4 v = *reinterpret_cast<const float4*>(lb + (wn * 64 + 32 * b + r) * LDS_N_STRIDE +
+        const float4 v = *reinterpret_cast<const float4*>(lb + (col_w + 32 * b + r) * LDS_N_STRIDE +
                                                           (16 * kq + 4 * q) * 4);
         bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          bf[b][t] = *reinterpret_cast<const float*>(lb + (16 * kq + 4 * q + t) * RS + (wn * 64 + 32 * b + r) * 4);
+          bf[b][t] = *reinterpret_cast<const float*>(lb + (16 * kq + 4 * q + t) * RS + (col_w + 32 * b + r) * 4);
       }
     }
 #pragma unroll
@@ -175,61 +167,60 @@ __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int
 #pragma unroll
       for (int a = 0; a < AB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
   }
 }
 
-template <int AB>
-__device__ __forceinline__ void zero_acc(d4 (&acc)[AB][4]) {
+template <int AB, int NB>
+__device__ __forceinline__ void zero_acc(d4 (&acc)[AB][NB]) {
 #pragma unroll
   for (int a = 0; a < AB; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NB; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 }
-template <int AB>
-__device__ __forceinline__ void zero_acc(f16v (&acc)[AB][2]) {
+template <int AB, int NB>
+__device__ __forceinline__ void zero_acc(f16v (&acc)[AB][NB]) {
 #pragma unroll
   for (int a = 0; a < AB; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 }
 
 // C/D maps: f64 16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg;
 //           f32 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-template <int AB>
-__device__ __forceinline__ void store_acc(double* __restrict__ C, long long ldc, int row0, int col0,
-                                          int wm, int wn, int lane, const d4 (&acc)[AB][4], double alpha,
-                                          double beta) {
+// row_g / col_g: global row / column of the wave's sub-tile origin.
+template <int AB, int NB>
+__device__ __forceinline__ void store_acc(double* __restrict__ C, long long ldc, int row_g, int col_g, int lane,
+                                          const d4 (&acc)[AB][NB], double alpha, double beta) {
 #pragma unroll
   for (int a = 0; a < AB; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wm * 16 * AB + 16 * a + (lane >> 4) + 4 * i;
-        const int col = col0 + wn * 64 + 16 * b + (lane & 15);
+        const int row = row_g + 16 * a + (lane >> 4) + 4 * i;
+        const int col = col_g + 16 * b + (lane & 15);
         double* p = C + (long long)row * ldc + col;
         double v = alpha * acc[a][b][i];
         if (beta != 0.0) v += beta * (*p);
         *p = v;
       }
 }
-template <int AB>
-__device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, int row0, int col0,
-                                          int wm, int wn, int lane, const f16v (&acc)[AB][2], double alpha,
-                                          double beta) {
+template <int AB, int NB>
+__device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, int row_g, int col_g, int lane,
+                                          const f16v (&acc)[AB][NB], double alpha, double beta) {
   const float al = (float)alpha, be = (float)beta;
 #pragma unroll
   for (int a = 0; a < AB; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = row0 + wm * 32 * AB + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const int col = col0 + wn * 64 + 32 * b + (lane & 31);
+        const int row = row_g + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int col = col_g + 32 * b + (lane & 31);
         float* p = C + (long long)row * ldc + col;
         float v = al * acc[a][b][i];
         if (be != 0.f) v += be * (*p);
@@ -237,15 +228,16 @@ __device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, 
       }
 }
 
-// Epilogue 1 (column sums of squares): instead of storing the 128 x 128 tile, store for each of its
-// 128 columns the sum over the tile's rows of (alpha * acc)^2, in fp64, at C[tile_row * ldc + col].
-// WM = wave rows of the workgroup (each contributes a partial per column).
-template <int AB, int WM>
+// Epilogue 1 (column sums of squares): instead of storing the tile, store for each of its TS columns the
+// sum over the tile's rows of (alpha * acc)^2, in fp64, at C[tile_row * ldc + col].  WM wave rows each
+// contribute a partial per column; col_w = the wave's column offset inside the tile.
+template <int AB, int NB, int WM, int TS>
 __device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, long long ldo, int tm, int col0,
-                                          int wm, int wn, int lane, int tid, const d4 (&acc)[AB][4], double alpha) {
-  double* red = reinterpret_cast<double*>(lds);   // [WM][128]
+                                          int wm, int col_w, int lane, int tid, const d4 (&acc)[AB][NB],
+                                          double alpha) {
+  double* red = reinterpret_cast<double*>(lds);   // [WM][TS]
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NB; ++b) {
     double s = 0.0;
 #pragma unroll
     for (int a = 0; a < AB; ++a)
@@ -253,63 +245,73 @@ __device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, l
       for (int i = 0; i < 4; ++i) { const double v = alpha * acc[a][b][i]; s = __builtin_fma(v, v, s); }
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (lane < 16) red[wm * 128 + wn * 64 + 16 * b + lane] = s;
+    if (lane < 16) red[wm * TS + col_w + 16 * b + lane] = s;
   }
   __syncthreads();
-  if (tid < 128) {
+  if (tid < TS) {
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < WM; ++w) t += red[w * 128 + tid];
+    for (int w = 0; w < WM; ++w) t += red[w * TS + tid];
     out[(long long)tm * ldo + col0 + tid] = t;
   }
 }
-template <int AB, int WM>
+template <int AB, int NB, int WM, int TS>
 __device__ __forceinline__ void sumsq_acc(char* lds, double* __restrict__ out, long long ldo, int tm, int col0,
-                                          int wm, int wn, int lane, int tid, const f16v (&acc)[AB][2], double alpha) {
+                                          int wm, int col_w, int lane, int tid, const f16v (&acc)[AB][NB],
+                                          double alpha) {
   double* red = reinterpret_cast<double*>(lds);
   const float al = (float)alpha;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < NB; ++b) {
     float s = 0.f;
 #pragma unroll
     for (int a = 0; a < AB; ++a)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { const float v = al * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
     s += __shfl_xor(s, 32, 64);
-    if (lane < 32) red[wm * 128 + wn * 64 + 32 * b + lane] = (double)s;
+    if (lane < 32) red[wm * TS + col_w + 32 * b + lane] = (double)s;
   }
   __syncthreads();
-  if (tid < 128) {
+  if (tid < TS) {
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < WM; ++w) t += red[w * 128 + tid];
+    for (int w = 0; w < WM; ++w) t += red[w * TS + tid];
     out[(long long)tm * ldo + col0 + tid] = t;
   }
 }
 
-// accumulator block grid per wave: rows of the wave tile / MFMA block rows
-template <typename T, int WM> struct AccT;
-template <int WM> struct AccT<double, WM> { static constexpr int AB = 128 / WM / 16; typedef d4 type[AB][4]; };
-template <int WM> struct AccT<float, WM> { static constexpr int AB = 128 / WM / 32; typedef f16v type[AB][2]; };
+// accumulator block grid of one wave: (TS/WM) x (TS/2) elements in MFMA blocks
+template <typename T, int WM, int TS> struct AccT;
+template <int WM, int TS> struct AccT<double, WM, TS> {
+  static constexpr int AB = TS / WM / 16, NB = TS / 2 / 16;
+  typedef d4 type[AB][NB];
+};
+template <int WM, int TS> struct AccT<float, WM, TS> {
+  static constexpr int AB = TS / WM / 32, NB = TS / 2 / 32;
+  typedef f16v type[AB][NB];
+};
 
-// WM wave rows x 2 wave columns: WM = 2 -> 256 threads, 64 x 64 per wave, 2 waves/SIMD at 2 workgroups/CU;
-//                                WM = 4 -> 512 threads, 32 x 64 per wave, 4 waves/SIMD (<= 128 VGPRs)
-template <typename T, bool TA, bool TB, int EPI, int WM>
-__global__ __launch_bounds__(WM * 128, WM) void gemm_kernel(KParams p) {
+// TS = 128: WM = 2 -> 256 threads, 64 x 64 per wave, 2 waves/SIMD at 2 workgroups/CU;
+//           WM = 4 -> 512 threads, 32 x 64 per wave, 4 waves/SIMD (<= 128 VGPRs)
+// TS =  64: WM = 2 -> 256 threads, 32 x 32 per wave, up to 4 workgroups/CU
+template <typename T, bool TA, bool TB, int EPI, int WM, int TS>
+__global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KParams p) {
+  constexpr int LDS_OP_BYTES = TS * LDS_N_STRIDE;   // also >= the k-strided image (BK rows of TS + 4 elements)
   __shared__ __attribute__((aligned(16))) char lds[4 * LDS_OP_BYTES];
   constexpr int BK = Cfg<T>::BK;
   constexpr int NT = WM * 128;
-  constexpr int AB = AccT<T, WM>::AB;
+  constexpr int AB = AccT<T, WM, TS>::AB, NB = AccT<T, WM, TS>::NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const int row_w = wm * (TS / WM), col_w = wn * (TS / 2);
 
   // ---- tile mapping.  Grids that fit one residency round (<= 512 tiles) map block -> tile directly.
   // Larger grids are cut into super-tiles of 64 tiles (8 x 8, or sr x 64/sr for short grids); hardware
-  // workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x takes super-tiles x, x+8, x+16, ...
-  // and walks the 64 tiles of one super-tile with its 64 resident workgroups (32 CUs x 2): the 8 + 8
-  // operand panels of a super-tile are shared through that XCD's L2, and every XCD sees an even
-  // sample of the tile grid (triangular problems stay balanced).  lower_only enumerates only the
-  // super-tiles on or below the diagonal.
+  // workgroup b runs on XCD b % 8 (round-robin dispatch, verified with HW_REG_XCC_ID), so XCD x takes
+  // super-tiles x, x+8, x+16, ... and walks the 64 tiles of one super-tile with its 64 resident
+  // workgroups: the 8 + 8 operand panels of a super-tile are shared through that XCD's L2, and every
+  // XCD sees an even sample of the tile grid (triangular problems stay balanced).  lower_only
+  // enumerates only the super-tiles on or below the diagonal.
   int tm, tn;
   if (p.direct) {
     tm = blockIdx.x % p.ntm;
@@ -337,8 +339,10 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_kernel(KParams p) {
   if (p.heavy_first) tm = p.ntm - 1 - tm;
   if (p.lower_only && tn > tm) return;
 
-  int kb = p.kb0 + p.kb_row * tm + p.kb_col * tn;
-  int ke = p.ke0 < 0 ? p.k : p.ke0 + p.ke_row * tm + p.ke_col * tn;
+  // k-range of this tile; the coefficients are given per 128-row tile index
+  const int tm128 = tm * TS / 128, tn128 = tn * TS / 128;
+  int kb = p.kb0 + p.kb_row * tm128 + p.kb_col * tn128;
+  int ke = p.ke0 < 0 ? p.k : p.ke0 + p.ke_row * tm128 + p.ke_col * tn128;
   kb = max(kb, 0);
   ke = min(ke, p.k);
   const int nkt = (ke - kb) / BK;
@@ -346,48 +350,49 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_kernel(KParams p) {
   const T* A = reinterpret_cast<const T*>(p.A);
   const T* B = reinterpret_cast<const T*>(p.B);
   T* C = reinterpret_cast<T*>(p.C);
-  const int row0 = tm * BM, col0 = tn * BN;
+  const int row0 = tm * TS, col0 = tn * TS;
 
-  typename AccT<T, WM>::type acc;
-  zero_acc<AB>(acc);
+  typename AccT<T, WM, TS>::type acc;
+  zero_acc<AB, NB>(acc);
 
   if (nkt > 0) {
     // Register-staged software pipeline ("write after the barrier"): at the top of iteration kt the
     // registers hold k-tile kt+1 (fetched during iteration kt-1's MFMAs); they are written to the
     // idle LDS buffer, the fetch of k-tile kt+2 is issued, and the MFMAs of k-tile kt run while it
     // is in flight.  One barrier per k-tile; tile indices are clamped so the body is branch-free.
-    V16 ra[1024 / NT], rb[1024 / NT];
-    load_tile<T, TA, NT>(A, p.lda, row0, kb, tid, ra);
-    load_tile<T, TB, NT>(B, p.ldb, col0, kb, tid, rb);
-    store_tile<T, TA, NT>(lds, tid, ra);
-    store_tile<T, TB, NT>(lds + LDS_OP_BYTES, tid, rb);
+    V16 ra[TS * 8 / NT], rb[TS * 8 / NT];
+    load_tile<T, TA, NT, TS>(A, p.lda, row0, kb, tid, ra);
+    load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb, tid, rb);
+    store_tile<T, TA, NT, TS>(lds, tid, ra);
+    store_tile<T, TB, NT, TS>(lds + LDS_OP_BYTES, tid, rb);
     {
       const int k1 = min(1, nkt - 1);
-      load_tile<T, TA, NT>(A, p.lda, row0, kb + k1 * BK, tid, ra);
-      load_tile<T, TB, NT>(B, p.ldb, col0, kb + k1 * BK, tid, rb);
+      load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + k1 * BK, tid, ra);
+      load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + k1 * BK, tid, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int cur = kt & 1;
-      store_tile<T, TA, NT>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
-      store_tile<T, TB, NT>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
+      store_tile<T, TA, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
+      store_tile<T, TB, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
       const int kn = min(kt + 2, nkt - 1);
-      load_tile<T, TA, NT>(A, p.lda, row0, kb + kn * BK, tid, ra);
-      load_tile<T, TB, NT>(B, p.ldb, col0, kb + kn * BK, tid, rb);
-      compute_tile<TA, TB, AB>(lds + cur * 2 * LDS_OP_BYTES, lds + cur * 2 * LDS_OP_BYTES + LDS_OP_BYTES, wm, wn,
-                           lane, acc);
+      load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + kn * BK, tid, ra);
+      load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + kn * BK, tid, rb);
+      compute_tile<TA, TB, AB, NB, TS>(lds + cur * 2 * LDS_OP_BYTES, lds + cur * 2 * LDS_OP_BYTES + LDS_OP_BYTES,
+                                       row_w, col_w, lane, acc);
       __syncthreads();
     }
   }
   if constexpr (EPI == 0) {
-    store_acc<AB>(C, p.ldc, row0, col0, wm, wn, lane, acc, p.alpha, p.beta);
+    store_acc<AB, NB>(C, p.ldc, row0 + row_w, col0 + col_w, lane, acc, p.alpha, p.beta);
   } else {
     // the k-loop ended with a barrier: the staging buffers are free for the reduction
-    sumsq_acc<AB, WM>(lds, reinterpret_cast<double*>(p.C), p.ldc, tm, col0, wm, wn, lane, tid, acc, p.alpha);
+    sumsq_acc<AB, NB, WM, TS>(lds, reinterpret_cast<double*>(p.C), p.ldc, tm, col0, wm, col_w, lane, tid, acc,
+                              p.alpha);
   }
 }
 
-template <typename T, int WM>
+template <typename T, int WM, int TS>
 int launch(gpk_handle h, const GemmArgs& g) {
   KParams p;
   p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
@@ -397,7 +402,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
   p.ke0 = g.ke0; p.ke_row = g.ke_row; p.ke_col = g.ke_col;
   p.heavy_first = g.heavy_first;
-  p.ntm = g.m / BM; p.ntn = g.n / BN;
+  p.ntm = g.m / TS; p.ntn = g.n / TS;
   const long long ntiles = g.lower_only ? (long long)p.ntm * (p.ntm + 1) / 2 : (long long)p.ntm * p.ntn;
   p.direct = ntiles <= 512 ? 1 : 0;
   p.sr = 8;
@@ -414,24 +419,31 @@ int launch(gpk_handle h, const GemmArgs& g) {
   dim3 grid((unsigned)nblocks), block(WM * 128);
   if (g.epilogue == 1) {
     if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }
-    if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1, WM>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<T, false, true, 1, WM>), grid, block, 0, h->stream, p);
+    if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1, WM, TS>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, false, true, 1, WM, TS>), grid, block, 0, h->stream, p);
     GPK_LAUNCH_CHECK(h);
     return GPK_OK;
   }
-  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 0, WM>), grid, block, 0, h->stream, p);
-  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, 0, WM>), grid, block, 0, h->stream, p);
-  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, 0, WM>), grid, block, 0, h->stream, p);
-  else hipLaunchKernelGGL((gemm_kernel<T, true, true, 0, WM>), grid, block, 0, h->stream, p);
+  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 0, WM, TS>), grid, block, 0, h->stream, p);
+  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, 0, WM, TS>), grid, block, 0, h->stream, p);
+  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, 0, WM, TS>), grid, block, 0, h->stream, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true, 0, WM, TS>), grid, block, 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }
 
 }  // namespace
 
+// tile edge gpk_gemm will use for this launch (callers that size per-tile-row outputs need it)
+int gpk_gemm_tile(gpk_handle h, const GemmArgs& g) {
+  const long long t128 = g.lower_only ? (long long)(g.m / 128) * (g.m / 128 + 1) / 2 : (long long)(g.m / 128) * (g.n / 128);
+  const bool aliased = g.C == g.A || g.C == g.B;
+  return (!aliased && t128 < h->gemm_small_tiles) ? 64 : 128;
+}
+
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   const int bk = dtype == GPK_F64 ? 16 : 32;
-  GPK_REQUIRE(h, g.m > 0 && g.n > 0 && g.m % BM == 0 && g.n % BN == 0, "gemm: m, n must be multiples of 128");
+  GPK_REQUIRE(h, g.m > 0 && g.n > 0 && g.m % 128 == 0 && g.n % 128 == 0, "gemm: m, n must be multiples of 128");
   GPK_REQUIRE(h, g.k >= 0 && g.k % bk == 0, "gemm: k must be a multiple of the k-tile");
   GPK_REQUIRE(h, g.kb0 % bk == 0 && g.kb_row % bk == 0 && g.kb_col % bk == 0 && (g.ke0 < 0 || g.ke0 % bk == 0) &&
                      g.ke_row % bk == 0 && g.ke_col % bk == 0,
@@ -439,8 +451,16 @@ int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   const int es = dtype == GPK_F64 ? 8 : 4;
   GPK_REQUIRE(h, (g.lda * es) % 16 == 0 && (g.ldb * es) % 16 == 0, "gemm: leading dimensions must be 16-byte multiples");
   GPK_REQUIRE(h, ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, "gemm: operands must be 16-byte aligned");
-  // wave rows per workgroup (2 -> 256 threads, 4 -> 512 threads), per dtype; tuned on MI355X,
+  // Small grids: a launch with fewer than h->gemm_small_tiles 128 x 128 tiles cannot occupy the 256 CUs; it runs
+  // on 64 x 64 tiles instead (4x the workgroups, ~3x lower latency).  In-place launches (C aliasing an operand:
+  // the 128-wide leaves of the triangular solves) rely on one tile covering everything it reads and keep 128.
+  const bool small = gpk_gemm_tile(h, g) == 64;
+  // wave rows per 128-tile workgroup (2 -> 256 threads, 4 -> 512 threads), per dtype; tuned on MI355X,
   // overridable through GPK_GEMM_WM_F64 / GPK_GEMM_WM_F32 (read once per handle)
-  if (dtype == GPK_F64) return h->gemm_wm_f64 == 2 ? launch<double, 2>(h, g) : launch<double, 4>(h, g);
-  return h->gemm_wm_f32 == 2 ? launch<float, 2>(h, g) : launch<float, 4>(h, g);
+  if (dtype == GPK_F64) {
+    if (small) return launch<double, 2, 64>(h, g);
+    return h->gemm_wm_f64 == 2 ? launch<double, 2, 128>(h, g) : launch<double, 4, 128>(h, g);
+  }
+  if (small) return launch<float, 2, 64>(h, g);
+  return h->gemm_wm_f32 == 2 ? launch<float, 2, 128>(h, g) : launch<float, 4, 128>(h, g);
 }

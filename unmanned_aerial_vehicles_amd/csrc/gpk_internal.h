@@ -23,6 +23,7 @@ struct gpk_context {
   double* h_small = nullptr;    // pinned host mirror
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
+  int gemm_small_tiles = 128;   // launches with fewer 128x128 tiles than this run on 64x64 tiles
 };
 
 #define GPK_CHECK_HIP(h, call)                                                          \
@@ -88,6 +89,7 @@ inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int
   return g;
 }
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);
+int gpk_gemm_tile(gpk_handle h, const GemmArgs& g);   // 128 or 64: the tile edge gpk_gemm will pick
 
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out);

@@ -248,6 +248,8 @@ class GaussianProcessRegressor:
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_dev"] = None
+        if not isinstance(st.get("device"), (int, type(None))):     # a private Backend (handle + stream): keep its index
+            st["device"] = getattr(st["device"], "device_index", None)
         st.pop("_rng", None)
         st["_alpha_host"] = None
         st["_L_host"] = None
