@@ -43,7 +43,7 @@ def main():
     import torch
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
-    from oracle.gp_oracle import synthetic_problem
+    from bench import synthetic_problem
     be = get_backend(0)
     out = {}
     if "gemm" in args.what:

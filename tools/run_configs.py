@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
     import torch
-    from oracle.gp_oracle import synthetic_problem
+    from bench import synthetic_problem
     from unmanned_aerial_vehicles_amd import (RBF, ConstantKernel, GaussianProcessRegressor, SimpleQuadrotorGP,
                                               WhiteKernel)
     from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
