@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--n-train", type=int, default=65536)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3 (default, the headline): mean+var for 10 000 queries per GPU per step, weak scaling; "
+                         "c4: BASELINE configs[3] - 1 048 576 queries in total sharded over the GPUs, posterior means "
+                         "only, RCCL all-gather of the means (strong scaling)")
     ap.add_argument("--var-method", default="inverse", choices=["inverse", "solve"],
                     help="inverse: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch (default); "
                          "solve: blocked triangular solve chain")
@@ -119,6 +123,9 @@ def main():
     from unmanned_aerial_vehicles_amd.sharded import all_gather_rows
 
     be = get_backend(local_rank)
+    c4 = args.workload == "c4"
+    if c4:
+        args.queries = (1 << 20) // world          # strong scaling: the 1 M queries are split over the ranks
     N, M, D, P = args.n_train, args.queries, 9, 3
     X, Y, _ = synthetic_problem(N, 1)
     Yn = (Y - Y.mean(0)) / Y.std(0)
@@ -155,7 +162,9 @@ def main():
     potrf_s = time.perf_counter() - t0
     dev.factored = True
     t0 = time.perf_counter()
-    if args.var_method == "inverse":
+    if c4:
+        trtri_s = None                             # means only: no variance preparation
+    elif args.var_method == "inverse":
         dev.inverse_factor(False)                  # W = L^-1 on the fp64 MFMA (N^3/3 flops) ...
         torch.cuda.synchronize()
         trtri_s = time.perf_counter() - t0
@@ -169,7 +178,7 @@ def main():
     dev.solve_alpha()                              # two launches through W when it exists, else the solve chain
     torch.cuda.synchronize()
     alpha_s = time.perf_counter() - t0
-    if args.var_method == "inverse":
+    if args.var_method == "inverse" and not c4:
         dev._Winv.pop("f64", None)                 # the fp64 inverse is not needed for fp32 serving
     dev._f32_data()
     torch.cuda.synchronize()
@@ -179,8 +188,9 @@ def main():
            "cholesky_s": potrf_s, "cholesky_GFLOPs": N ** 3 / 3.0 / potrf_s / 1e9,
            "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
            "alpha_solve_ms": alpha_s * 1e3,
-           "variance_prep": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy"
-                            if args.var_method == "inverse" else "fp32 copy of L",
+           "variance_prep": "none (means only)" if c4 else
+                            ("explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy"
+                             if args.var_method == "inverse" else "fp32 copy of L"),
            "variance_prep_s": prep_s, "trtri_s": trtri_s,
            "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None}
 
@@ -188,7 +198,11 @@ def main():
     kss = sf2 + noise
     ystd2 = torch.as_tensor(y_std ** 2, device=be.device, dtype=torch.float64)
 
-    def step():
+    def step_c4():
+        mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4 only
+        return all_gather_rows(mean, M * world) if use_dist else mean
+
+    def step_c3():
         mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4
         var = dev.predict_var_dev(q32, kss, 0.0, "float32", args.var_method)        # K5
         out = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1)      # (M, 2P)
@@ -196,6 +210,7 @@ def main():
             out = all_gather_rows(out, M * world)                                   # RCCL all-gather
         return out
 
+    step = step_c4 if c4 else step_c3
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -216,7 +231,19 @@ def main():
     # The K5 call is bracketed with HIP events on the launch stream; besides the GEMM it contains the
     # K*-build (~1 ms) and two tiny reductions, so the figure is slightly conservative.
     roof = None
-    if rank == 0:
+    if rank == 0 and c4:
+        # K4 is VALU/transcendental-bound: algorithmic flops M N (3D + 2P + 8) against the fp32 vector peak
+        flops = float(M) * N * (3 * D + 2 * P + 8)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dev.predict_mean_dev(q32, y_mean, y_std, "float32")
+        b.record()
+        torch.cuda.synchronize()
+        k4_s = a.elapsed_time(b) * 1e-3
+        roof = {"bound": "valu", "kernel": "predict_mean_kernel<float,3,1>", "achieved": flops / k4_s / 1e12,
+                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / k4_s / 1e12 / MFMA_F32_PEAK_TF,
+                "traffic": None, "k4_ms": k4_s * 1e3, "algorithmic_flops_per_step": flops}
+    if rank == 0 and not c4:
         Mp = padded(M)
         lsv = np.full(D, ls)
         lsp = lsv.ctypes.data_as(_lib._dp)
@@ -260,20 +287,25 @@ def main():
     if rank == 0:
         total_pred = float(M) * world * args.steps
         line = {
-            "metric": "GP predictions/sec (mean+var) at N_train=65536, D=9",
+            "metric": "GP predictions/sec (mean+var) at N_train=65536, D=9" if not c4 else
+                      "GP predictions/sec (posterior means, 1M queries sharded) at N_train=65536, D=9",
             "value": total_pred / dt, "unit": "predictions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if c4 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: N_train={N}, D={D}, P={P}, batched predict mean+var over {M} query points "
-                                   f"per GPU per step (horizon 20 x 500 rollouts), fp32 predict on an fp64 factor",
+            "config": {"workload": (f"C3: N_train={N}, D={D}, P={P}, batched predict mean+var over {M} query points "
+                                    f"per GPU per step (horizon 20 x 500 rollouts), fp32 predict on an fp64 factor")
+                                   if not c4 else
+                                   (f"C4: N_train={N}, D={D}, P={P}, {M * world} queries sharded over {world} GPU(s), "
+                                    f"posterior means, fp32, all-gather of the means"),
                        "n_train": N, "features": D, "outputs": P, "queries_per_gpu_per_step": M,
                        "parallelism": f"query-sharded x{world}, model replicated" +
-                                      (", RCCL all-gather of [mean|var]" if use_dist else "")},
+                                      ((", RCCL all-gather of the means" if c4 else ", RCCL all-gather of [mean|var]")
+                                       if use_dist else "")},
             "roofline": roof,
             "fit": fit,
         }
-        if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not c4:     # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -201,13 +201,13 @@ class DeviceGP:
                 be.bind_stream()
                 be.check(be.lib.gpk_potrs(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self.Yn), self.N,
                                           self.P, _p(self.alpha)))
-        self._f32 = None if self._f32 is None else {k: v for k, v in self._f32.items() if k not in ("alpha",)}
-        if self._f32 is not None and "X" not in self._f32:
-            self._f32 = None
+        if self._f32:
+            self._f32.pop("alpha", None)       # the fp32 copy of alpha is stale; X / L copies stay valid
 
     def set_alpha(self, alpha):
         self.alpha.copy_(self.be.upload(np.asarray(alpha, dtype=np.float64).reshape(self.N, self.P)))
-        self._f32 = None
+        if self._f32:
+            self._f32.pop("alpha", None)
 
     def lml_terms(self):
         """K6a: (sum log diag L, [y_p . alpha_p])."""
