@@ -108,3 +108,53 @@ def test_simple_gp_swallows_failures(csv_data):
     m, v = gp.predict_residual(np.zeros(5), np.zeros(4))          # wrong width -> fallback, no exception
     assert not m.any() and (v == 1).all()
     assert gp.load_model("/nonexistent/model.pkl") is False
+
+
+def test_predict_during_refit_threads(csv_data):
+    """The package GP is refitted on a timer thread while a subscription thread predicts
+    (quadrotor_gp_mpc/quadrotor_gp_mpc/main.py:818-826, unlocked in the reference).  Here fit() builds a new
+    device model and swaps it in atomically: concurrent predicts never fail and always come from one
+    consistent model (old or new)."""
+    import threading
+    from unmanned_aerial_vehicles_amd import GaussianProcess
+    X, Y = csv_data["X10"][:400, :9], csv_data["Y6"][:400, 3:6]
+    g = GaussianProcess(input_dim=9, output_dim=3)
+    g.add_training_data(X[:200], Y[:200])
+    g.fit()
+    xq = X[5:6]
+    m_old = g.predict(xq)[0].copy()
+    g2 = GaussianProcess(input_dim=9, output_dim=3)
+    g2.add_training_data(X, Y)
+    g2.fit()
+    m_new = g2.predict(xq)[0].copy()
+    errors, seen = [], set()
+    stop = threading.Event()
+
+    def predictor():
+        while not stop.is_set():
+            try:
+                m, v = g.predict(xq)
+                if np.allclose(m, m_old, rtol=1e-12, atol=1e-15):
+                    seen.add("old")
+                elif np.allclose(m, m_new, rtol=1e-12, atol=1e-15):
+                    seen.add("new")
+                else:
+                    errors.append(("mixed", m.copy()))
+                if not (np.isfinite(v).all() and (v > 0).all()):
+                    errors.append(("var", v.copy()))
+            except Exception as e:  # noqa: BLE001
+                errors.append(("exc", repr(e)))
+
+    t = threading.Thread(target=predictor)
+    t.start()
+    try:
+        for _ in range(5):
+            g.X_train, g.Y_train = X[:200], Y[:200]
+            g.fit()
+            g.X_train, g.Y_train = X, Y
+            g.fit()
+    finally:
+        stop.set()
+        t.join(30)
+    assert not errors, errors[:3]
+    assert "new" in seen or "old" in seen
