@@ -36,7 +36,7 @@ typedef struct gpk_context* gpk_handle;
 
 enum { GPK_F32 = 0, GPK_F64 = 1 };
 enum { GPK_OK = 0, GPK_NOT_PD = 1, GPK_BAD_ARG = 2, GPK_HIP_ERROR = 3 };
-enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_P = 16 };
+enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_P = 16, GPK_MAX_BATCH = 8 };
 
 /* ---- context ------------------------------------------------------------------ */
 int gpk_create(gpk_handle* h, int device);
@@ -49,6 +49,18 @@ const char* gpk_last_error(gpk_handle h);
 int gpk_set_stream(gpk_handle h, void* stream);
 int gpk_synchronize(gpk_handle h);
 int64_t gpk_padded(int64_t n);
+
+/* ---- batched mode: `count` (<= 8) same-shaped problems per call --------------------------------------
+ * Between gpk_batch_begin and gpk_batch_end, gpk_potrf, gpk_leaf_inverses, gpk_trtri, gpk_wtw and
+ * gpk_potrs_inv work on `count` independent problems with ONE launch chain: every kernel of the chain
+ * gets a batch grid dimension.  The pointer arguments address problem 0; a pointer that lies inside a
+ * buffer registered with gpk_batch_buffer(base, stride_bytes) advances by that stride per problem, any
+ * other pointer is shared by all problems.  gpk_potrf's `info` then receives `count` entries.
+ * (BASELINE configuration 5: the per-axis ax/ay/az GPs of src/px4/gp_trainer.py:139-179 factorised
+ * together.)                                                                                          */
+int gpk_batch_begin(gpk_handle h, int count);
+int gpk_batch_buffer(gpk_handle h, const void* base, int64_t stride_bytes);
+int gpk_batch_end(gpk_handle h);
 const char* gpk_version(void);
 
 /* ---- K1: RBF Gram build ---------------------------------------------------------

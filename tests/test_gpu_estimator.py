@@ -293,10 +293,17 @@ def test_batched_per_axis_ard_gps(csv_data, ka):
         assert relerr(mean, per_model) < 1e-12
         mean2, std = bg.predict(Xq, return_std=True)
         assert relerr(std[:, 0], ka["ka6b_std"]) < TOL
-        lml, grad = bg.log_marginal_likelihood(bg.thetas, eval_gradient=True)
-        assert lml.shape == (3,) and grad.shape == (3, 10)
-        assert abs(lml[0] - ka["ka6b_lml"]) < 1e-10 * abs(lml[0])
-        assert relerr(grad[0], ka["ka6b_grad"]) < 1e-8
+        for fused in (True, False):
+            lml, grad = bg.log_marginal_likelihood(bg.thetas, eval_gradient=True, fused=fused)
+            assert lml.shape == (3,) and grad.shape == (3, 10)
+            assert abs(lml[0] - ka["ka6b_lml"]) < 1e-10 * abs(lml[0])
+            assert relerr(grad[0], ka["ka6b_grad"]) < 1e-8
+        # the fused (one launch chain for all models) and per-model paths agree, also at distinct thetas
+        th = bg.thetas + np.array([[0.0], [0.3], [-0.2]])
+        l1, g1 = bg.log_marginal_likelihood(th, eval_gradient=True, fused=True)
+        l2, g2 = bg.log_marginal_likelihood(th, eval_gradient=True, fused=False)
+        assert relerr(l1, l2) < 1e-12 and relerr(g1, g2) < 1e-9
+        assert relerr(bg.log_marginal_likelihood(th), l2) < 1e-12
     bg3 = pickle.loads(pickle.dumps(bg))                 # models carry a private backend: must still pickle
     assert relerr(bg3.predict(Xq), mean) < 1e-12
     # fp32 fused predict

@@ -149,9 +149,13 @@ def main():
         bg = BatchedARDGP(length_scale=ls, noise_level=0.1, alpha=1e-4, normalize_y=True, optimizer=None,
                           predict_dtype="float32").fit(X, Y)
         th = bg.thetas
-        t, (bl, bgr) = wall(lambda: bg.log_marginal_likelihood(th, eval_gradient=True), reps=2)
-        c5[f"N{N5}"]["three_gps_concurrent_s"] = t
+        t, (bl, bgr) = wall(lambda: bg.log_marginal_likelihood(th, eval_gradient=True, fused=False), reps=2)
+        c5[f"N{N5}"]["three_gps_concurrent_streams_s"] = t
+        bg.log_marginal_likelihood(th, eval_gradient=True, fused=True)
+        t, (bl, bgr) = wall(lambda: bg.log_marginal_likelihood(th, eval_gradient=True, fused=True), reps=2)
+        c5[f"N{N5}"]["three_gps_fused_batch_s"] = t
         c5[f"N{N5}"]["lml_batched_matches"] = bool(np.allclose(bl, lmls, rtol=1e-12))
+        bg.release_fused_buffers()
         Xq5 = np.random.default_rng(1).standard_normal((10000, 9))
         q5 = torch.as_tensor(Xq5, dtype=torch.float32, device=be.device)
         bg.predict_mean_dev(q5)

@@ -27,6 +27,9 @@ SIGNATURES = {
     "gpk_set_stream": (_int, [_vp, _vp]),
     "gpk_synchronize": (_int, [_vp]),
     "gpk_padded": (_i64, [_i64]),
+    "gpk_batch_begin": (_int, [_vp, _int]),
+    "gpk_batch_buffer": (_int, [_vp, _vp, _i64]),
+    "gpk_batch_end": (_int, [_vp]),
     "gpk_version": (C.c_char_p, []),
     "gpk_gram": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _i64]),
     "gpk_cross_gram_t": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _int, _dp, _dbl, _vp, _i64]),

@@ -33,10 +33,11 @@ class BatchedARDGP:
         self.models = []
         self._workers = []
         self._fused = None
+        self._fs = None
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        st["_workers"], st["_fused"] = [], None          # handles, streams and device tensors are rebuilt lazily
+        st["_workers"], st["_fused"], st["_fs"] = [], None, None   # handles, streams, device tensors: rebuilt lazily
         return st
 
     # ------------------------------------------------------------------ workers
@@ -90,12 +91,17 @@ class BatchedARDGP:
 
         self.models = self._map(one, B)
         self._fused = None
+        self._fs = None
         return self
 
-    def log_marginal_likelihood(self, thetas, eval_gradient=False):
+    def log_marginal_likelihood(self, thetas, eval_gradient=False, fused=True):
         """thetas: (B, D+1) log-parameters [log ls_0..log ls_{D-1}, log noise] per model.
-        Returns lml (B,) and, with eval_gradient, grad (B, D+1) — the hyper-parameter step of config 5."""
+        Returns lml (B,) and, with eval_gradient, grad (B, D+1) — the hyper-parameter step of config 5.
+        fused=True: the B factorisations, inversions and alpha solves share ONE launch chain (every kernel gets
+        a batch grid dimension, `gpk_batch_begin`); fused=False: one chain per model on its own stream."""
         thetas = np.asarray(thetas, dtype=np.float64)
+        if fused:
+            return self._lml_fused(thetas, eval_gradient)
 
         def one(b):
             g = self.models[b]
@@ -107,6 +113,75 @@ class BatchedARDGP:
         if not eval_gradient:
             return np.array(res)
         return np.array([r[0] for r in res]), np.stack([r[1] for r in res])
+
+    def _fused_state(self):
+        """Stacked HBM buffers for the batched launch chain: K/L, leaf inverses, W = L^-1, K^-1, scratch."""
+        import torch
+        if getattr(self, "_fs", None) is None:
+            m0 = self.models[0]
+            for m in self.models:
+                m._ensure_device()
+            be = get_backend(self.device)
+            B, N, D = len(self.models), m0._dev.N, m0._dev.D
+            Np = m0._dev.Np
+            tsz = (Np // 2 + 128) ** 2
+            f64 = torch.float64
+            self._fs = {
+                "be": be, "B": B, "N": N, "D": D, "Np": Np, "tsz": tsz,
+                "X": m0._dev.X.to(be.device),
+                "Yn": torch.stack([m._dev.Yn[:, 0].to(be.device) for m in self.models]).contiguous(),   # (B, N)
+                "K": be.empty((B, Np, Np), f64), "winv": be.empty((B, Np, 128), f64),
+                "W": be.empty((B, Np, Np), f64), "Kinv": be.empty((B, Np, Np), f64),
+                "T": be.empty((B, tsz), f64), "alpha": be.empty((B, N), f64),
+            }
+        return self._fs
+
+    def _lml_fused(self, thetas, eval_gradient):
+        fs = self._fused_state()
+        be, B, N, D, Np = fs["be"], fs["B"], fs["N"], fs["D"], fs["Np"]
+        lib, dp = be.lib, _lib._dp
+        comps = [self.models[b].kernel_.clone_with_theta(thetas[b]).components() for b in range(B)]
+        ls = [np.ascontiguousarray(c.ls_vector(D)) for c in comps]
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        info = (C.c_int * B)()
+        with be.lock:
+            be.bind_stream()
+            for b in range(B):       # K1 per model (one launch each)
+                be.check(lib.gpk_gram(be.h, _lib.GPK_F64, p(fs["X"]), N, D, ls[b].ctypes.data_as(dp), comps[b].sf2,
+                                      (comps[b].noise or 0.0) + float(self.alpha), p(fs["K"][b]), Np))
+            be.check(lib.gpk_batch_begin(be.h, B))
+            try:
+                for name, row_bytes in (("K", Np * Np * 8), ("winv", Np * 128 * 8), ("W", Np * Np * 8),
+                                        ("Kinv", Np * Np * 8), ("T", fs["tsz"] * 8), ("Yn", N * 8), ("alpha", N * 8)):
+                    be.check(lib.gpk_batch_buffer(be.h, p(fs[name]), row_bytes))
+                rc = lib.gpk_potrf(be.h, p(fs["K"]), Np, Np, p(fs["winv"]), info)          # K2, B problems
+                if rc not in (_lib.GPK_OK, _lib.GPK_NOT_PD):
+                    be.check(rc)
+                be.check(lib.gpk_trtri(be.h, p(fs["K"]), Np, Np, p(fs["winv"]), p(fs["W"]), Np, p(fs["T"])))
+                be.check(lib.gpk_potrs_inv(be.h, p(fs["W"]), Np, Np, p(fs["Yn"]), N, 1, p(fs["alpha"])))   # K3
+                if eval_gradient:
+                    be.check(lib.gpk_wtw(be.h, p(fs["W"]), Np, Np, p(fs["Kinv"]), Np))
+            finally:
+                lib.gpk_batch_end(be.h)
+            lml = np.full(B, -np.inf)
+            grad = np.zeros((B, thetas.shape[1]))
+            terms = np.zeros(2)
+            g = np.zeros(D + 2)
+            for b in range(B):
+                if info[b] != 0:       # not positive definite: (-inf, 0) as sklearn/_gpr.py:588-589
+                    continue
+                be.check(lib.gpk_lml_terms(be.h, p(fs["K"][b]), N, Np, p(fs["Yn"][b]), p(fs["alpha"][b]), 1,
+                                           terms.ctypes.data_as(dp)))
+                lml[b] = -0.5 * terms[1] - terms[0] - 0.5 * N * np.log(2.0 * np.pi)
+                if eval_gradient:
+                    be.check(lib.gpk_lml_grad(be.h, p(fs["X"]), N, D, ls[b].ctypes.data_as(dp), comps[b].sf2,
+                                              comps[b].noise or 0.0, p(fs["alpha"][b]), 1, p(fs["Kinv"][b]), Np,
+                                              g.ctypes.data_as(dp)))
+                    grad[b] = comps[b].map_gradient(g, D)
+        return (lml, grad) if eval_gradient else lml
+
+    def release_fused_buffers(self):
+        self._fs = None
 
     @property
     def thetas(self):

@@ -16,7 +16,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   gpk_context* h = new gpk_context();
   h->device = device;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&h->d_info, sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->d_info, GPK_MAX_BATCH * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->d_small, 4096) != hipSuccess ||
       hipHostMalloc((void**)&h->h_small, 4096, hipHostMallocDefault) != hipSuccess) {
     delete h;
@@ -52,6 +52,28 @@ extern "C" int gpk_set_stream(gpk_handle h, void* stream) {
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   h->stream = want;
   h->user_stream = (stream != GPK_OWN_STREAM);
+  return GPK_OK;
+}
+
+extern "C" int gpk_batch_begin(gpk_handle h, int count) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, count >= 1 && count <= GPK_MAX_BATCH, "batch_begin: count must be in [1, 8]");
+  GPK_REQUIRE(h, h->batch == 1 && h->bbufs.empty(), "batch_begin: a batch is already open");
+  h->batch = count;
+  return GPK_OK;
+}
+
+extern "C" int gpk_batch_buffer(gpk_handle h, const void* base, int64_t stride_bytes) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, base && stride_bytes > 0 && stride_bytes % 16 == 0, "batch_buffer: stride must be a positive multiple of 16");
+  h->bbufs.push_back({(const char*)base, (long long)stride_bytes});
+  return GPK_OK;
+}
+
+extern "C" int gpk_batch_end(gpk_handle h) {
+  if (!h) return GPK_BAD_ARG;
+  h->batch = 1;
+  h->bbufs.clear();
   return GPK_OK;
 }
 

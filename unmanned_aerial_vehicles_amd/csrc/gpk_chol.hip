@@ -31,8 +31,13 @@ constexpr int LSA = 130;   // LDS row stride of the 128 x 128 image
 constexpr int LSW = 18;    // row stride of the 16 x 16 diagonal inverses
 
 template <bool FACTOR>
-__global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A, long long lda, int row0,
-                                                   int* __restrict__ info, double* __restrict__ W) {
+__global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long long lda, int row0,
+                                                   int* __restrict__ info0, double* __restrict__ W0,
+                                                   long long strideA, long long strideW) {
+  // one workgroup per problem of the batch (strides in bytes)
+  double* __restrict__ A = reinterpret_cast<double*>(reinterpret_cast<char*>(A0) + blockIdx.x * strideA);
+  double* __restrict__ W = reinterpret_cast<double*>(reinterpret_cast<char*>(W0) + blockIdx.x * strideW);
+  int* __restrict__ info = info0 + blockIdx.x;
   __shared__ __attribute__((aligned(16))) double a[NB * LSA];
   __shared__ __attribute__((aligned(16))) double wd[8 * 16 * LSW];   // wd[b][r][c] = W_bb[c][r]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,7 +185,10 @@ __global__ void to_f32_kernel(const double* __restrict__ a, long long n, float* 
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) b[e] = (float)a[e];
 }
-__global__ void copy_leaf_kernel(const double* __restrict__ w, double* __restrict__ W, long long ldw) {
+__global__ void copy_leaf_kernel(const double* __restrict__ w0, double* __restrict__ W0, long long ldw,
+                                 long long stride_w, long long stride_W) {
+  const double* __restrict__ w = reinterpret_cast<const double*>(reinterpret_cast<const char*>(w0) + blockIdx.y * stride_w);
+  double* __restrict__ W = reinterpret_cast<double*>(reinterpret_cast<char*>(W0) + blockIdx.y * stride_W);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= NB * NB) return;
   const int i = e >> 7, j = e & 127;
@@ -230,8 +238,8 @@ int trsm_right_rec(gpk_handle h, double* B, int64_t ldb, int64_t m, const double
 
 int potrf_rec(gpk_handle h, double* A, int64_t lda, int64_t n, double* winv, int64_t row0) {
   if (n == NB) {
-    hipLaunchKernelGGL(leaf_kernel<true>, dim3(1), dim3(256), 0, h->stream, A, (long long)lda, (int)row0, h->d_info,
-                       winv);
+    hipLaunchKernelGGL(leaf_kernel<true>, dim3(h->batch), dim3(256), 0, h->stream, A, (long long)lda, (int)row0,
+                       h->d_info, winv, gpk_bstride(h, A), gpk_bstride(h, winv));
     GPK_LAUNCH_CHECK(h);
     return GPK_OK;
   }
@@ -280,7 +288,8 @@ int trsm_left_t_rec(gpk_handle h, double* B, int64_t ldb, int64_t M, const doubl
 int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const double* winv, double* W, int64_t ldw,
               double* T, int64_t ldt) {
   if (n == NB) {
-    hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256), dim3(256), 0, h->stream, winv, W, (long long)ldw);
+    hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, h->batch), dim3(256), 0, h->stream, winv, W,
+                       (long long)ldw, gpk_bstride(h, winv), gpk_bstride(h, W));
     GPK_LAUNCH_CHECK(h);
     return GPK_OK;
   }
@@ -304,12 +313,17 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, doubl
   GPK_REQUIRE(h, A && winv && info, "potrf: null pointer");
   GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && lda >= Np && lda % 2 == 0, "potrf: Np must be a positive multiple of 128");
   GPK_REQUIRE(h, Np < (1ll << 31), "potrf: Np too large");
-  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  const int nb = h->batch;                         // batched mode: info receives one entry per problem
+  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, nb * sizeof(int), h->stream));
   GPK_TRY(potrf_rec(h, A, lda, Np, winv, 0));
-  int hinfo = 0;
-  GPK_CHECK_HIP(h, hipMemcpyAsync(&hinfo, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  int hinfo_all[GPK_MAX_BATCH] = {0};
+  GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo_all, h->d_info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-  *info = hinfo;
+  int hinfo = 0;
+  for (int b = 0; b < nb; ++b) {
+    info[b] = hinfo_all[b];
+    if (hinfo == 0 && hinfo_all[b] != 0) hinfo = hinfo_all[b];
+  }
   if (hinfo != 0) {
     char buf[160];
     snprintf(buf, sizeof buf, "matrix is not positive definite: leading minor of order %d has a non-positive pivot", hinfo);
@@ -324,9 +338,9 @@ extern "C" int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int6
   GPK_REQUIRE(h, L && winv, "leaf_inverses: null pointer");
   GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && ldl >= Np, "leaf_inverses: Np must be a positive multiple of 128");
   for (int64_t b = 0; b < Np / NB; ++b) {
-    hipLaunchKernelGGL(leaf_kernel<false>, dim3(1), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(leaf_kernel<false>, dim3(h->batch), dim3(256), 0, h->stream,
                        const_cast<double*>(L) + b * NB * ldl + b * NB, (long long)ldl, 0, h->d_info,
-                       winv + b * NB * NB);
+                       winv + b * NB * NB, gpk_bstride(h, L), gpk_bstride(h, winv));
     GPK_LAUNCH_CHECK(h);
   }
   return GPK_OK;
@@ -440,23 +454,38 @@ extern "C" int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t 
   GPK_REQUIRE(h, W && Y && alpha, "potrs_inv: null pointer");
   GPK_REQUIRE(h, Np % NB == 0 && N >= 1 && N <= Np && ldw >= Np, "potrs_inv: bad sizes");
   GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P, "potrs_inv: P must be in [1, 16]");
+  const int nb = h->batch;
+  const long long panel = Np * NB;                         // doubles per problem and panel
   void* ws = nullptr;
-  GPK_TRY(gpk_scratch(h, (size_t)2 * Np * NB * sizeof(double), &ws));
+  GPK_TRY(gpk_scratch(h, (size_t)2 * nb * panel * sizeof(double), &ws));
   double* Yp = (double*)ws;
-  double* Z = Yp + Np * NB;
-  const long long tot = Np * NB;
-  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, Y,
-                     (long long)N, P, Yp, (long long)Np);
-  GPK_LAUNCH_CHECK(h);
+  double* Z = Yp + (long long)nb * panel;
+  const long long sY = gpk_bstride(h, Y) / (long long)sizeof(double), sAl = gpk_bstride(h, alpha) / (long long)sizeof(double);
+  for (int b = 0; b < nb; ++b) {
+    hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((panel + 255) / 256)), dim3(256), 0, h->stream, Y + b * sY,
+                       (long long)N, P, Yp + b * panel, (long long)Np);
+    GPK_LAUNCH_CHECK(h);
+  }
+  // the two panels are per-problem scratch: register them for the duration of the two launches
+  if (nb > 1) {
+    h->bbufs.push_back({(const char*)Yp, panel * (long long)sizeof(double)});
+    h->bbufs.push_back({(const char*)Z, panel * (long long)sizeof(double)});
+  }
   // Z = W Yp   (W lower: k < row-tile end), then Yp = W^T Z   (k >= row-tile start): two launches
   GemmArgs g1 = gemm_args(W, ldw, 0, Yp, NB, 1, Z, NB, (int)Np, NB, (int)Np, 1.0, 0.0);
   g1.ke0 = NB; g1.ke_row = NB; g1.heavy_first = 1;
-  GPK_TRY(gpk_gemm(h, GPK_F64, g1));
-  GemmArgs g2 = gemm_args(W, ldw, 1, Z, NB, 1, Yp, NB, (int)Np, NB, (int)Np, 1.0, 0.0);
-  g2.kb_row = NB;
-  GPK_TRY(gpk_gemm(h, GPK_F64, g2));
-  hipLaunchKernelGGL(unpack_rhs_kernel, dim3((unsigned)((N * P + 255) / 256)), dim3(256), 0, h->stream,
-                     (const double*)Yp, (long long)N, P, alpha);
-  GPK_LAUNCH_CHECK(h);
+  int rc = gpk_gemm(h, GPK_F64, g1);
+  if (rc == GPK_OK) {
+    GemmArgs g2 = gemm_args(W, ldw, 1, Z, NB, 1, Yp, NB, (int)Np, NB, (int)Np, 1.0, 0.0);
+    g2.kb_row = NB;
+    rc = gpk_gemm(h, GPK_F64, g2);
+  }
+  if (nb > 1) { h->bbufs.pop_back(); h->bbufs.pop_back(); }
+  GPK_TRY(rc);
+  for (int b = 0; b < nb; ++b) {
+    hipLaunchKernelGGL(unpack_rhs_kernel, dim3((unsigned)((N * P + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double*)(Yp + b * panel), (long long)N, P, alpha + b * sAl);
+    GPK_LAUNCH_CHECK(h);
+  }
   return GPK_OK;
 }

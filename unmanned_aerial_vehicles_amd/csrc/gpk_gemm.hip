@@ -28,6 +28,7 @@ struct KParams {
   const char* B;
   char* C;
   long long lda, ldb, ldc;  // in elements
+  long long sA, sB, sC;     // byte strides between the problems of a batch (blockIdx.y)
   int m, n, k;
   double alpha, beta;
   int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;   // k-range coefficients per 128-row tile index
@@ -347,9 +348,10 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   ke = min(ke, p.k);
   const int nkt = (ke - kb) / BK;
 
-  const T* A = reinterpret_cast<const T*>(p.A);
-  const T* B = reinterpret_cast<const T*>(p.B);
-  T* C = reinterpret_cast<T*>(p.C);
+  const long long by = blockIdx.y;
+  const T* A = reinterpret_cast<const T*>(p.A + by * p.sA);
+  const T* B = reinterpret_cast<const T*>(p.B + by * p.sB);
+  T* C = reinterpret_cast<T*>(p.C + by * p.sC);
   const int row0 = tm * TS, col0 = tn * TS;
 
   typename AccT<T, WM, TS>::type acc;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     store_acc<AB, NB>(C, p.ldc, row0 + row_w, col0 + col_w, lane, acc, p.alpha, p.beta);
   } else {
     // the k-loop ended with a barrier: the staging buffers are free for the reduction
-    sumsq_acc<AB, NB, WM, TS>(lds, reinterpret_cast<double*>(p.C), p.ldc, tm, col0, wm, col_w, lane, tid, acc,
+    sumsq_acc<AB, NB, WM, TS>(lds, reinterpret_cast<double*>(C), p.ldc, tm, col0, wm, col_w, lane, tid, acc,
                               p.alpha);
   }
 }
@@ -397,6 +399,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   KParams p;
   p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
   p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
+  p.sA = gpk_bstride(h, g.A); p.sB = gpk_bstride(h, g.B); p.sC = gpk_bstride(h, g.C);
   p.m = g.m; p.n = g.n; p.k = g.k;
   p.alpha = g.alpha; p.beta = g.beta;
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
@@ -416,7 +419,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.nst = g.lower_only ? nsr * (nsr + 1) / 2 : nsr * p.nsc;
   const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
   if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
-  dim3 grid((unsigned)nblocks), block(WM * 128);
+  dim3 grid((unsigned)nblocks, (unsigned)h->batch), block(WM * 128);
   if (g.epilogue == 1) {
     if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }
     if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1, WM, TS>), grid, block, 0, h->stream, p);

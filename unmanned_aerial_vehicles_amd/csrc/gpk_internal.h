@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/gpk.h"
 
@@ -23,7 +24,13 @@ struct gpk_context {
   double* h_small = nullptr;    // pinned host mirror
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
-  int gemm_small_tiles = 128;   // launches with fewer 128x128 tiles than this run on 64x64 tiles
+  int gemm_small_tiles = 128;
+  // batched mode (gpk_batch_begin .. gpk_batch_end): `batch` same-shaped problems per call.  Pointers passed
+  // to the entry points address problem 0; a pointer that falls inside a registered buffer advances by that
+  // buffer's stride per problem, any other pointer is shared by all problems.
+  struct BatchBuf { const char* base; long long stride; };
+  int batch = 1;
+  std::vector<BatchBuf> bbufs;   // launches with fewer 128x128 tiles than this run on 64x64 tiles
 };
 
 #define GPK_CHECK_HIP(h, call)                                                          \
@@ -59,6 +66,15 @@ struct gpk_context {
   } while (0)
 
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
+
+// byte stride between consecutive problems of a batch for the buffer `p` points into (0: shared / not batched)
+inline long long gpk_bstride(gpk_handle h, const void* p) {
+  if (h->batch <= 1) return 0;
+  const char* c = (const char*)p;
+  for (const auto& b : h->bbufs)
+    if (c >= b.base && c < b.base + b.stride) return b.stride;
+  return 0;
+}
 
 // ---- dense GEMM on MFMA (gpk_gemm.hip) ---------------------------------------------
 // C[m x n] = alpha * opA(A) * opB(B)^T + beta * C on whole 128x128 tiles.
