@@ -76,22 +76,62 @@ class BatchedARDGP:
 
     # ------------------------------------------------------------------ fit / LML
     def fit(self, X, Y):
+        """Fit B single-output ARD GPs on the shared inputs X (N, D); Y is (N, B).
+
+        With the L-BFGS-B optimiser and B > 1 the hyper-parameters of all models are optimised together: the
+        objective is the sum of the B log-marginal likelihoods (block-separable, so the joint optimum is the
+        per-model optimum) and every evaluation is ONE fused launch chain for all models.  Restarts draw a new
+        start for every model at once and each model keeps its best run."""
+        import scipy.optimize
         X = np.asarray(X, dtype=np.float64)
         Y = np.asarray(Y, dtype=np.float64).reshape(len(X), -1)
         B, D = Y.shape[1], X.shape[1]
         if B > 8:
             raise ValueError("at most 8 models per batch")
+        joint = self.optimizer == "fmin_l_bfgs_b" and B > 1
 
         def one(b):
             be = self._backend(b)[0]
             g = GaussianProcessRegressor(kernel=self._kernel(D), alpha=self.alpha, normalize_y=self.normalize_y,
-                                         optimizer=self.optimizer, n_restarts_optimizer=self.n_restarts_optimizer,
+                                         optimizer=None if joint else self.optimizer,
+                                         n_restarts_optimizer=self.n_restarts_optimizer,
                                          device=be, predict_dtype=self.predict_dtype)
             return g.fit(X, Y[:, b])
 
         self.models = self._map(one, B)
         self._fused = None
         self._fs = None
+        if joint:
+            nth = self.models[0].kernel_.n_dims
+            bounds = np.tile(self.models[0].kernel_.bounds, (B, 1))
+
+            def obj(flat):
+                lml, grad = self._lml_fused(flat.reshape(B, nth), True)
+                lml = np.where(np.isfinite(lml), lml, -1e25)          # a not-PD model: large penalty, zero gradient
+                return -float(np.sum(lml)), -grad.reshape(-1)
+
+            rng = np.random.mtrand._rand
+            best_theta = self.thetas.copy()
+            best_lml = np.full(B, -np.inf)
+            starts = [self.thetas.reshape(-1)]
+            starts += [rng.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(self.n_restarts_optimizer)]
+            for x0 in starts:
+                res = scipy.optimize.minimize(obj, x0, method="L-BFGS-B", jac=True, bounds=bounds)
+                th = res.x.reshape(B, nth)
+                lml = self._lml_fused(th, False)
+                better = lml > best_lml
+                best_theta[better], best_lml[better] = th[better], lml[better]
+            self.release_fused_buffers()
+
+            def finish(b):
+                g = self.models[b]
+                g.kernel_.theta = best_theta[b]
+                g.log_marginal_likelihood_value_ = float(best_lml[b])
+                g._refactor()
+                g._alpha_host = g._L_host = None
+                return g
+
+            self.models = self._map(finish, B)
         return self
 
     def log_marginal_likelihood(self, thetas, eval_gradient=False, fused=True):
