@@ -240,6 +240,16 @@ def test_per_output_trainer(csv_data, tmp_path):
     assert mean.shape == (6,) and std.shape == (6,) and np.isfinite(mean).all()
     mb, sb = pg.predict_residual_batch(X[:7])
     assert np.allclose(mb[5], mean) and np.allclose(sb[5], std)
+    mf, _ = pg.predict_residual_batch(X[:7], return_std=False)          # fused one-launch means
+    assert pg._fused() and np.allclose(mf, mb, rtol=1e-10, atol=1e-14)
+    # the joint (batched) optimiser is at least as good as the reference's one-by-one training
+    # (multi-start L-BFGS-B: local optima may differ slightly between the two)
+    tr2 = GPTrainer(model_dir=str(tmp_path))
+    np.random.seed(1)
+    stats2 = tr2.train_gp_models(X, Y, n_restarts_optimizer=1, batched=False)
+    for name in stats:
+        a, b = stats[name]["log_marginal_likelihood"], stats2[name]["log_marginal_likelihood"]
+        assert a >= b - 0.01 * abs(b) - 1e-3
 
 
 def test_full_size_properties():
