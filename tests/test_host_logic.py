@@ -18,11 +18,11 @@ def test_c_abi_exports_every_declared_symbol():
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(gpk_[a-z0-9_]+)\s*\(", header))
     assert len(declared) >= 20
+    lib2 = _lib.load()                      # (imports torch first: one HIP runtime per process)
     lib = ctypes.CDLL(_build.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gpk.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    lib2 = _lib.load()
     assert lib2.gpk_padded(1000) == 1024 and lib2.gpk_padded(128) == 128 and lib2.gpk_padded(1) == 128
     assert b"gfx950" in lib2.gpk_version()
 

@@ -75,6 +75,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (libamdhip64): it must be in the process BEFORE libgpk.so is
+    # dlopen'ed, so that libgpk binds to that same runtime (one HIP context, shared streams and allocations).
+    # Loading libgpk first would pull in the system runtime and leave torch without a usable device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
