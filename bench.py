@@ -284,6 +284,23 @@ def main():
                 "algorithmic_flops_per_step": flops}
         del work, var
 
+    # host-boundary rate (not the headline): queries start in host memory, results end in host memory
+    host_api = None
+    if rank == 0 and world == 1 and not c4:
+        xq_host = np.ascontiguousarray(Xq, dtype=np.float32)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            qd = torch.from_numpy(xq_host).to(be.device)
+            mean = dev.predict_mean_dev(qd, y_mean, y_std, "float32")
+            var = dev.predict_var_dev(qd, kss, 0.0, "float32", args.var_method)
+            res = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1).cpu().numpy()
+            ts.append(time.perf_counter() - t0)
+        host_api = {"ms_per_batch": min(ts) * 1e3, "predictions_per_s": M / min(ts),
+                    "note": "PCIe-inclusive: 10 000 x 9 fp32 queries host->HBM, (10 000 x 6) fp64 results HBM->host"}
+        assert np.isfinite(res).all()
+
     if rank == 0:
         total_pred = float(M) * world * args.steps
         line = {
@@ -304,6 +321,7 @@ def main():
                                        if use_dist else "")},
             "roofline": roof,
             "fit": fit,
+            "host_api": host_api,
         }
         if not args.no_cpu_baseline and world == 1 and not c4:     # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline()
