@@ -132,6 +132,17 @@ int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, 
                      int P, const double* ls, double sf2, const double* y_mean,
                      const double* y_std, const void* Xq, int64_t M, void* mean);
 
+/* K4 on the matrix cores, fp32 only: the same posterior mean as gpk_predict_mean(GPK_F32, ...), with the
+ * pairwise squared distances of 32 x 32 (query, training point) blocks formed by v_mfma_f32_32x32x2_f32
+ * from centred, scaled coordinates (|a|^2 + |b|^2 - 2 a.b: one augmented dot product of length D + 1) and
+ * only exp2 + P FMAs per pair left on the vector ALU.  center: host double[D], a point near the data (the
+ * training mean); the expansion is accurate to ~|u|^2 * 2^-23 in the exponent, u = (x - center) / ls, so
+ * callers use it while max |u|^2 is modest (device.py: <= 64) and the exact-difference kernel otherwise.
+ * D <= 16, P <= 8.  Replaces the same reference lines as gpk_predict_mean.                              */
+int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,
+                          const double* ls, double sf2, const double* center, const double* y_mean,
+                          const double* y_std, const float* Xq, int64_t M, float* mean);
+
 /* K4 for B (<= 8) independent single-output ARD models that share X (the per-axis GPs of
  * src/px4/gp_trainer.py:139-179, predicted one by one at src/px4/pretrained_gp.py:64-91): one launch
  * evaluates every model; the feature differences of a (query, training point) pair are formed once.

@@ -224,6 +224,38 @@ def test_predict_mean_fp64_fp32(be, csv_data, ka):
         assert relerr(out, O.predict(st, q)) < 1e-11
 
 
+@pytest.mark.parametrize("N,D,P,M,ls", [(1000, 9, 3, 257, 2.0), (5000, 9, 3, 10000, 2.0), (777, 10, 6, 25, 1.5),
+                                         (300, 16, 8, 7, 3.0), (129, 1, 1, 1, 0.7), (2048, 4, 4, 600, 1.0),
+                                         (640, 15, 5, 130, 2.5)])
+def test_predict_mean_mfma(be, N, D, P, M, ls):
+    """K4 on the matrix cores (fp32, centred expansion of the squared distance) against the fp64 oracle
+    and the exact-difference fp32 kernel: same posterior mean within the fp32 tolerance (1e-4 of the
+    largest mean; measured ~1e-6), on ragged shapes, every operand-depth variant (D + 1 odd and even) and
+    both query-block layouts (P <= 4, P > 4)."""
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(N + D)
+    X = rng.standard_normal((N, D)) + 3.0 * np.arange(D)      # off-centre columns: the kernel re-centres them
+    Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+    lsv = np.full(D, ls) * (1.0 + 0.05 * np.arange(D))
+    st = O.fit_fixed(X, Y, lsv, 1.3, 0.1, 1e-4)
+    dev = DeviceGP(X, st.Yn, be)
+    dev.ls, dev.sf2 = lsv, 1.3
+    dev.set_alpha(st.alpha)
+    assert dev.mean_kernel_choice() == "mfma"
+    Xq = rng.standard_normal((M, D)) + 3.0 * np.arange(D)
+    ref = O.predict(st, Xq).reshape(M, P)
+    scale = np.max(np.abs(ref))
+    m_mfma = dev.predict_mean_dev(Xq, st.y_mean, st.y_std, "float32", "mfma").double().cpu().numpy()
+    m_valu = dev.predict_mean_dev(Xq, st.y_mean, st.y_std, "float32", "valu").double().cpu().numpy()
+    assert np.max(np.abs(m_valu - ref)) < 1e-4 * scale
+    assert np.max(np.abs(m_mfma - ref)) < 1e-4 * scale
+    auto = dev.predict_mean_dev(Xq, st.y_mean, st.y_std, "float32").double().cpu().numpy()
+    assert np.array_equal(auto, m_mfma)
+    # widely spread data relative to the length-scale: the gate falls back to exact differences
+    dev.ls = np.full(D, 0.02)
+    assert dev.mean_kernel_choice() == "valu"
+
+
 def test_lml_gradient_kernels(be, csv_data, ka):
     from unmanned_aerial_vehicles_amd.device import DeviceGP
     X, Y = csv_data["X10"][:, :9], csv_data["Y6"][:, 3:6]

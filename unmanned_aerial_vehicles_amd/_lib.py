@@ -42,6 +42,7 @@ SIGNATURES = {
     "gpk_trsm_lower_left": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _vp, _i64, _i64]),
     "gpk_colsumsq": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp]),
     "gpk_predict_mean": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _vp]),
+    "gpk_predict_mean_mfma": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_mean_multi": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,
                                _dbl, _vp, _vp]),
@@ -82,11 +83,12 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("GPK_LIBRARY") or LIB_PATH      # GPK_LIBRARY: an experimental build (see _build.build)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the GP kernels)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -1,0 +1,476 @@
+// K4 on the matrix cores (fp32 serving path): posterior mean  mu = K(Xq, X) alpha  with the pairwise
+// squared distances of 32 x 32 (query, training point) blocks formed by MFMAs instead of D subtract/FMA
+// pairs per (query, point) on the vector ALU.
+//
+// With u = sqrt(log2(e)/2) * (x - c) / ls (c = a common centre: the training mean) the kernel value is
+//   k = exp2(-d),  d = |u_q|^2 + |u_j|^2 - 2 u_q . u_j
+// and d is ONE augmented dot product of depth D + 1 plus an accumulator seed:
+//   A (queries, m) = [ u_q (D) | 1 | 0.. ],  B (training, n) = [ -2 u_j (D) | |u_j|^2 | 0.. ],  C_init[m][n] = |u_q|^2
+// Per pair only v_exp_f32 + P FMAs remain on the vector ALU.
+//
+//  * D <= 15 (mean_bf16_kernel): the dot product runs on the bf16 matrix pipe at fp32 accuracy.  Every fp32
+//    operand is split EXACTLY into three bf16 parts (x = x0 + x1 + x2, 8 significant bits each, by
+//    truncation; the remainders are exact in fp32) and the product becomes six v_mfma_f32_32x32x16_bf16
+//    (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0; the dropped terms are below 2^-24 of |a||b|; bf16 x bf16
+//    products are exact and accumulate in fp32): 192 matrix-pipe cycles per block.
+//  * D = 16 (mean_mfma_kernel, depth 17): nine v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  That
+//    instruction runs at the vector rate and was measured NOT to overlap with the exp/FMA work (it shares
+//    the fp32 lanes), which is why the bf16 split is preferred wherever the depth fits one instruction.
+//
+// The expansion loses ~|u|^2 * 2^-23 absolutely in d, so the caller centres the data and uses this path only
+// while max |u|^2 is modest (device.py gates on it); the exact-difference VALU kernel in gpk_gram.hip serves
+// everything else and all of fp64.
+//
+// Accumulator layout of a 32 x 32 block (C/D map of the 32x32 MFMAs): lane l, register r holds
+// (query row (r & 3) + 8 (r >> 2) + 4 (l >> 5), training point l & 31): a lane keeps ONE training point per
+// block, so alpha_j are per-lane values and its 16 x P running sums belong to 16 queries; the 32 lanes of a
+// half-wave are combined once, after the loop over the training chunk.  Measured on MI355X (N = 65536,
+// D = 9, P = 3, 2^20 queries): 15.4 ms against 46.6 ms for the VALU kernel; vector-ALU bound.
+//
+// Reference: the mean of sklearn _gpr.py:443-447 / RBF.__call__ kernels.py:1564-1565 and
+// quadrotor_gp_mpc/gaussian_process.py:223-226 (same value; fp32 arithmetic).
+#include "gpk_internal.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int MM_TJ = 512;        // training points staged per LDS round
+
+struct F16 { float v[16]; };
+struct D16 { double v[16]; };
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// One pipeline step: issue the KP-MFMA chain of the NEXT (points, queries) block and, in between its
+// instructions, turn the finished block `cur` into kernel values and accumulate them:
+// acc[r][p] += exp2(-cur[r]) * av[p].  Returns the new chain's accumulator.
+template <int KP, int PP>
+__device__ __forceinline__ f16v mean_step(const float (&a)[KP], const float (&bf)[KP], const f16v& seed, const f16v& cur,
+                                          const float (&av)[PP], float (&acc)[16][PP]) {
+  f16v nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bf[0], seed, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    if (i > 0) nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bf[i], nxt, 0, 0, 0);
+#pragma unroll
+    for (int r = 16 * i / KP; r < 16 * (i + 1) / KP; ++r) {
+      const float e = __builtin_amdgcn_exp2f(-cur[r]);
+#pragma unroll
+      for (int p = 0; p < PP; ++p) acc[r][p] = __builtin_fmaf(e, av[p], acc[r][p]);
+    }
+  }
+  return nxt;
+}
+
+// QB query blocks of 32 per wave (4 waves: 128 * QB queries per workgroup); PP outputs (exact)
+template <int KP, int PP, int QB>
+__global__ __launch_bounds__(256, 2) void mean_mfma_kernel(const float* __restrict__ X, const float* __restrict__ alpha,
+                                                           long long N, int D, F16 sc, F16 ctr,
+                                                           const float* __restrict__ Xq, long long M, long long chunk,
+                                                           float* __restrict__ partial) {
+  __shared__ float xt[2 * KP][MM_TJ];      // row k: B operand component k of every staged point
+  __shared__ float al[PP][MM_TJ];
+  __shared__ float qn_s[128 * QB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, lh = lane >> 5;
+  const long long q0 = (long long)blockIdx.x * (128 * QB);
+
+  // ---- query side: norms through LDS, A fragments and accumulator seeds in registers
+  for (int t = tid; t < 128 * QB; t += 256) {
+    const long long q = q0 + t;
+    float s = 0.f;
+    if (q < M)
+      for (int d = 0; d < D; ++d) {
+        const float u = (Xq[q * D + d] - ctr.v[d]) * sc.v[d];
+        s = __builtin_fmaf(u, u, s);
+      }
+    qn_s[t] = s;
+  }
+  float a[QB][KP];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const long long q = q0 + (wave * QB + b) * 32 + ln;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const int k = 2 * i + lh;
+      float v = 0.f;
+      if (q < M) {
+        if (k < D) v = (Xq[q * D + k] - ctr.v[k]) * sc.v[k];
+        else if (k == D) v = 1.f;
+      }
+      a[b][i] = v;
+    }
+  }
+  __syncthreads();
+  f16v seed[QB];
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seed[b][r] = qn_s[(wave * QB + b) * 32 + acc_row(r, lane)];
+
+  float acc[QB][16][PP];
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int p = 0; p < PP; ++p) acc[b][r][p] = 0.f;
+
+  const long long n0 = (long long)blockIdx.y * chunk;
+  const long long n1 = min(N, n0 + chunk);
+  for (long long jb = n0; jb < n1; jb += MM_TJ) {
+    __syncthreads();
+    // ---- stage MM_TJ training points: [-2 u | |u|^2 | 0] and alpha (zero beyond the chunk)
+    for (int t = tid; t < MM_TJ; t += 256) {
+      const long long j = jb + t;
+      const bool in = j < n1;
+      float tn = 0.f;
+      for (int d = 0; d < D; ++d) {
+        const float u = in ? (X[j * D + d] - ctr.v[d]) * sc.v[d] : 0.f;
+        tn = __builtin_fmaf(u, u, tn);
+        xt[d][t] = -2.f * u;
+      }
+      xt[D][t] = tn;
+      if (D + 1 < 2 * KP) xt[D + 1][t] = 0.f;
+#pragma unroll
+      for (int p = 0; p < PP; ++p) al[p][t] = in ? alpha[j * PP + p] : 0.f;
+    }
+    __syncthreads();
+    const int nblk = (int)((min((long long)MM_TJ, n1 - jb) + 31) / 32);
+
+    // ---- software pipeline over (block of 32 points, query block) steps: the MFMA chain of the next step is
+    // issued in between the exp/FMA work on the current one (mean_step), so the matrix core and the vector
+    // ALU of the SIMD run side by side within a wave
+    float bf[KP], av[PP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) bf[i] = xt[2 * i + lh][ln];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) av[p] = al[p][ln];
+    f16v cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], bf[0], seed[0], 0, 0, 0);
+#pragma unroll
+    for (int i = 1; i < KP; ++i) cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][i], bf[i], cur, 0, 0, 0);
+    for (int jj = 0; jj < nblk; ++jj) {
+      // fragments of the next block of points (clamped on the last one: its chain is discarded)
+      const int jn = min(jj + 1, nblk - 1) * 32 + ln;
+      float bfn[KP], avn[PP];
+#pragma unroll
+      for (int i = 0; i < KP; ++i) bfn[i] = xt[2 * i + lh][jn];
+#pragma unroll
+      for (int p = 0; p < PP; ++p) avn[p] = al[p][jn];
+      if constexpr (QB == 2) {
+        cur = mean_step<KP, PP>(a[1], bf, seed[1], cur, av, acc[0]);
+      }
+      cur = mean_step<KP, PP>(a[0], bfn, seed[0], cur, av, acc[QB - 1]);
+#pragma unroll
+      for (int i = 0; i < KP; ++i) bf[i] = bfn[i];
+#pragma unroll
+      for (int p = 0; p < PP; ++p) av[p] = avn[p];
+    }
+  }
+
+  // ---- combine the 32 lanes of each half-wave (they hold different training points of the same 16 queries)
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int p = 0; p < PP; ++p) {
+        float v = acc[b][r][p];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        acc[b][r][p] = v;
+      }
+  if (ln == 0) {
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long q = q0 + (wave * QB + b) * 32 + acc_row(r, lane);
+        if (q < M) {
+#pragma unroll
+          for (int p = 0; p < PP; ++p) partial[((long long)blockIdx.y * M + q) * PP + p] = acc[b][r][p];
+        }
+      }
+  }
+}
+
+// ---- D <= 15: distances on the bf16 matrix pipe, exact three-way operand split ----------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h0);
+  h1 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(h1);
+  h2 = __float_as_uint(r2);          // at most 8 significant bits left: the low half is zero
+}
+// three bf16x8 fragments (k = 0..7 of this lane's half) from eight fp32 values
+__device__ __forceinline__ void split_frag(const float (&v)[8], u32x4 (&f)[3]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    split3(v[2 * j], a0, a1, a2);
+    split3(v[2 * j + 1], b0, b1, b2);
+    f[0][j] = (a0 >> 16) | b0;
+    f[1][j] = (a1 >> 16) | b1;
+    f[2][j] = (a2 >> 16) | (b2 & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ f16v chain6(const u32x4 (&a)[3], const u32x4 (&b)[3], const f16v& seed) {
+  const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[0]), a1 = __builtin_bit_cast(bf16x8, a[1]),
+               a2 = __builtin_bit_cast(bf16x8, a[2]);
+  const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]),
+               b2 = __builtin_bit_cast(bf16x8, b[2]);
+  f16v c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, seed, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+  return c;
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+// acc[i][p] holds the running sums of accumulator rows 2i (x) and 2i + 1 (y): one v_pk_fma_f32 per row pair
+// and output, with alpha_p broadcast to both halves
+template <int PP>
+__device__ __forceinline__ void consume(const f16v& cur, const float (&av)[PP], f2 (&acc)[8][PP]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f2 e;
+    e.x = __builtin_amdgcn_exp2f(-cur[2 * i]);
+    e.y = __builtin_amdgcn_exp2f(-cur[2 * i + 1]);
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const f2 a2 = {av[p], av[p]};
+      acc[i][p] = __builtin_elementwise_fma(e, a2, acc[i][p]);
+    }
+  }
+}
+
+// D <= 15 (operand depth D + 1 <= 16).  LDS image of a staged point block (32 points): [part][half][point] x 16 B.
+template <int PP, int QB>
+__global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restrict__ X, const float* __restrict__ alpha,
+                                                           long long N, int D, F16 sc, F16 ctr,
+                                                           const float* __restrict__ Xq, long long M, long long chunk,
+                                                           float* __restrict__ partial) {
+  __shared__ u32x4 xb[MM_TJ / 32][3][2][32];
+  __shared__ float al[PP][MM_TJ];
+  __shared__ float qn_s[128 * QB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, lh = lane >> 5;
+  const long long q0 = (long long)blockIdx.x * (128 * QB);
+
+  for (int t = tid; t < 128 * QB; t += 256) {
+    const long long q = q0 + t;
+    float s = 0.f;
+    if (q < M)
+      for (int d = 0; d < D; ++d) {
+        const float u = (Xq[q * D + d] - ctr.v[d]) * sc.v[d];
+        s = __builtin_fmaf(u, u, s);
+      }
+    qn_s[t] = s;
+  }
+  u32x4 a[QB][3];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const long long q = q0 + (wave * QB + b) * 32 + ln;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lh + j;
+      v[j] = 0.f;
+      if (q < M) {
+        if (k < D) v[j] = (Xq[q * D + k] - ctr.v[k]) * sc.v[k];
+        else if (k == D) v[j] = 1.f;
+      }
+    }
+    split_frag(v, a[b]);
+  }
+  __syncthreads();
+  f16v seed[QB];
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seed[b][r] = qn_s[(wave * QB + b) * 32 + acc_row(r, lane)];
+
+  f2 acc[QB][8][PP];
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int p = 0; p < PP; ++p) acc[b][i][p] = f2{0.f, 0.f};
+
+  const long long n0 = (long long)blockIdx.y * chunk;
+  const long long n1 = min(N, n0 + chunk);
+  for (long long jb = n0; jb < n1; jb += MM_TJ) {
+    __syncthreads();
+    // ---- stage: point t -> components [-2 u (D) | |u|^2 | 0 ...] (16), split, as two 8-wide halves
+    for (int t = tid; t < MM_TJ; t += 256) {
+      const long long j = jb + t;
+      const bool in = j < n1;
+      float v[16];
+      float tn = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        float u = 0.f;
+        if (d < D && in) u = (X[j * D + d] - ctr.v[d]) * sc.v[d];
+        tn = __builtin_fmaf(u, u, tn);
+        v[d] = -2.f * u;
+      }
+#pragma unroll
+      for (int d = 0; d < 16; ++d)
+        if (d == D) v[d] = tn;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float vh[8];
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) vh[j8] = v[8 * h + j8];
+        u32x4 f[3];
+        split_frag(vh, f);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) xb[t >> 5][s3][h][t & 31] = f[s3];
+      }
+#pragma unroll
+      for (int p = 0; p < PP; ++p) al[p][t] = in ? alpha[j * PP + p] : 0.f;
+    }
+    __syncthreads();
+    const int nblk = (int)((min((long long)MM_TJ, n1 - jb) + 31) / 32);
+
+    u32x4 bf[3];
+    float av[PP];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) bf[s3] = xb[0][s3][lh][ln];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) av[p] = al[p][ln];
+    f16v cur = chain6(a[0], bf, seed[0]);
+    for (int jj = 0; jj < nblk; ++jj) {
+      const int jn = min(jj + 1, nblk - 1);
+      u32x4 bfn[3];
+      float avn[PP];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) bfn[s3] = xb[jn][s3][lh][ln];
+#pragma unroll
+      for (int p = 0; p < PP; ++p) avn[p] = al[p][jn * 32 + ln];
+      if constexpr (QB == 2) {
+        const f16v nxt = chain6(a[1], bf, seed[1]);
+        consume<PP>(cur, av, acc[0]);
+        cur = nxt;
+      }
+      const f16v nxt = chain6(a[0], bfn, seed[0]);     // (discarded after the last block)
+      consume<PP>(cur, av, acc[QB - 1]);
+      cur = nxt;
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) bf[s3] = bfn[s3];
+#pragma unroll
+      for (int p = 0; p < PP; ++p) av[p] = avn[p];
+    }
+  }
+
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v[PP];
+#pragma unroll
+      for (int p = 0; p < PP; ++p) {
+        float t = (r & 1) ? acc[b][r >> 1][p].y : acc[b][r >> 1][p].x;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        v[p] = t;
+      }
+      const long long q = q0 + (wave * QB + b) * 32 + acc_row(r, lane);
+      if (ln == 0 && q < M) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) partial[((long long)blockIdx.y * M + q) * PP + p] = v[p];
+      }
+    }
+}
+
+__global__ void mean_mfma_reduce_kernel(const float* __restrict__ partial, int S, long long M, int P, float sf2,
+                                        D16 ymean, D16 ystd, float* __restrict__ mean) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * P) return;
+  const int p = (int)(e % P);
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += partial[(long long)k * M * P + e];
+  mean[e] = (float)ymean.v[p] + (float)ystd.v[p] * (sf2 * s);
+}
+
+typedef void (*mm_fn)(const float*, const float*, long long, int, F16, F16, const float*, long long, long long, float*);
+
+template <int KP>
+mm_fn mm_pick_p(int P) {
+  switch (P) {
+    case 1: return mean_mfma_kernel<KP, 1, 2>;
+    case 2: return mean_mfma_kernel<KP, 2, 2>;
+    case 3: return mean_mfma_kernel<KP, 3, 2>;
+    case 4: return mean_mfma_kernel<KP, 4, 1>;
+    case 5: return mean_mfma_kernel<KP, 5, 1>;
+    case 6: return mean_mfma_kernel<KP, 6, 1>;
+    case 7: return mean_mfma_kernel<KP, 7, 1>;
+    default: return mean_mfma_kernel<KP, 8, 1>;
+  }
+}
+mm_fn mm_pick_bf16(int P) {
+  switch (P) {
+    case 1: return mean_bf16_kernel<1, 2>;
+    case 2: return mean_bf16_kernel<2, 2>;
+    case 3: return mean_bf16_kernel<3, 2>;
+    case 4: return mean_bf16_kernel<4, 1>;
+    case 5: return mean_bf16_kernel<5, 1>;
+    case 6: return mean_bf16_kernel<6, 1>;
+    case 7: return mean_bf16_kernel<7, 1>;
+    default: return mean_bf16_kernel<8, 1>;
+  }
+}
+}  // namespace
+
+extern "C" int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,
+                                     const double* ls, double sf2, const double* center, const double* y_mean,
+                                     const double* y_std, const float* Xq, int64_t M, float* mean) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && alpha && Xq && mean && ls && center && y_mean && y_std, "predict_mean_mfma: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1, "predict_mean_mfma: empty input");
+  GPK_REQUIRE(h, D >= 1 && D <= 16, "predict_mean_mfma: D must be in [1, 16]");
+  GPK_REQUIRE(h, P >= 1 && P <= 8, "predict_mean_mfma: P must be in [1, 8]");
+  F16 sc{}, ctr{};
+  D16 ym{}, ys{};
+  const double s = 0.84932180028801904;   // sqrt(log2(e) / 2)
+  for (int d = 0; d < D; ++d) {
+    GPK_REQUIRE(h, ls[d] > 0.0, "predict_mean_mfma: length scales must be positive");
+    sc.v[d] = (float)(s / ls[d]);
+    ctr.v[d] = (float)center[d];
+  }
+  for (int p = 0; p < P; ++p) { ym.v[p] = y_mean[p]; ys.v[p] = y_std[p]; }
+  const int QB = P <= 3 ? 2 : 1;   // must match mm_pick_p / mm_pick_bf16
+  const int64_t nqb = (M + 128 * QB - 1) / (128 * QB);
+  // split the training set so that the grid has >= ~1024 workgroups (2 resident per CU, 2 rounds)
+  int64_t S = (1024 + nqb - 1) / nqb;
+  const int64_t maxS = (N + MM_TJ - 1) / MM_TJ;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  if (S > 65535) S = 65535;
+  int64_t chunk = (N + S - 1) / S;
+  chunk = (chunk + MM_TJ - 1) / MM_TJ * MM_TJ;
+  S = (N + chunk - 1) / chunk;
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)S * M * P * sizeof(float), &partial));
+  // D <= 15: distances on the bf16 matrix cores (exact three-way operand split, depth D + 1 <= 16);
+  // D = 16: depth 17, nine fp32 MFMAs
+  hipLaunchKernelGGL(D > 15 ? mm_pick_p<9>(P) : mm_pick_bf16(P), dim3((unsigned)nqb, (unsigned)S), dim3(256), 0, h->stream, X, alpha,
+                     (long long)N, D, sc, ctr, Xq, (long long)M, (long long)chunk, (float*)partial);
+  GPK_LAUNCH_CHECK(h);
+  const int64_t tot = M * P;
+  hipLaunchKernelGGL(mean_mfma_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                     (const float*)partial, (int)S, (long long)M, P, (float)sf2, ym, ys, mean);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}

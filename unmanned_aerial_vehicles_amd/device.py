@@ -122,6 +122,9 @@ class DeviceGP:
         if not (1 <= self.P <= _lib.GPK_MAX_P):
             raise ValueError(f"P must be in [1, {_lib.GPK_MAX_P}]")
         self.Np = padded(self.N)
+        self._Xh = X                      # host copy: spread statistics that gate the MFMA mean kernel
+        self._xc = X.mean(axis=0)
+        self._r2 = {}
         self.X = self.be.upload(X)
         self.Yn = self.be.upload(Yn)
         self.K = None       # (Np, Np) f64: Gram, then L
@@ -286,10 +289,29 @@ class DeviceGP:
             raise ValueError(f"queries must be (M, {self.D})")
         return q
 
-    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64"):
-        """K4 on device tensors; returns a (M, P) tensor of `dtype`."""
+    # the fp32 MFMA mean kernel expands |a - b|^2 = |a|^2 + |b|^2 - 2 a.b around the training mean; it is used
+    # while the largest scaled squared norm (in exp2 units) stays below this bound (error in the exponent
+    # ~ bound * 2^-22), the exact-difference kernel otherwise
+    MFMA_MEAN_R2_MAX = 64.0
+
+    def mean_kernel_choice(self):
+        """"mfma" if the fp32 matrix-core mean kernel is admissible for the current length-scales."""
+        key = self.ls.tobytes()
+        if key not in self._r2:
+            u = (self._Xh - self._xc) / self.ls
+            self._r2 = {key: 0.5 * np.log2(np.e) * float(np.max(np.einsum("ij,ij->i", u, u)))}
+        return "mfma" if (self.P <= 8 and self._r2[key] <= self.MFMA_MEAN_R2_MAX) else "valu"
+
+    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64", kernel="auto"):
+        """K4 on device tensors; returns a (M, P) tensor of `dtype`.  kernel: "valu" (exact differences on
+        the vector ALU), "mfma" (fp32 only: distances on the matrix cores) or "auto" (mfma for fp32 when
+        `mean_kernel_choice` admits it)."""
         torch = _torch()
         f32 = dtype in ("float32", np.float32, torch.float32)
+        if kernel == "auto":
+            kernel = self.mean_kernel_choice() if f32 else "valu"
+        if kernel not in ("valu", "mfma") or (kernel == "mfma" and not f32):
+            raise ValueError("kernel must be 'auto', 'valu' or 'mfma' (mfma: float32 only)")
         tdt = torch.float32 if f32 else torch.float64
         q = self._as_queries(Xq, tdt)
         M = q.shape[0]
@@ -304,6 +326,14 @@ class DeviceGP:
         ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
         ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
         be = self.be
+        if kernel == "mfma":
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_predict_mean_mfma(be.h, _p(Xd), _p(ad), self.N, self.D, self.P,
+                                                      self.ls.ctypes.data_as(_lib._dp), self.sf2,
+                                                      self._xc.ctypes.data_as(_lib._dp), ym.ctypes.data_as(_lib._dp),
+                                                      ys.ctypes.data_as(_lib._dp), _p(q), M, _p(out)))
+            return out
         with be.lock:
             be.bind_stream()
             be.check(be.lib.gpk_predict_mean(be.h, GPK_F32 if f32 else GPK_F64, _p(Xd), _p(ad), self.N, self.D,
