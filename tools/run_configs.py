@@ -187,9 +187,12 @@ def main():
     dev.solve_alpha()
     q = torch.randn((M, 9), dtype=torch.float32, device=be.device)
     t, _ = wall(lambda: dev.predict_mean_dev(q, np.zeros(3), np.ones(3), "float32"), reps=3)
+    tv, _ = wall(lambda: dev.predict_mean_dev(q, np.zeros(3), np.ones(3), "float32", "valu"), reps=3)
     flops = float(M) * N * (3 * 9 + 2 * 3 + 8)
-    res["C4_single_gpu"] = {"queries": M, "n_train": N, "mean_only_s": t, "pred_per_s": M / t,
-                            "algorithmic_TFLOPs": flops / t / 1e12, "frac_of_fp32_vector_peak": flops / t / 1e12 / 157.3}
+    res["C4_single_gpu"] = {"queries": M, "n_train": N, "kernel": dev.mean_kernel_choice(), "mean_only_s": t,
+                            "pred_per_s": M / t, "algorithmic_TFLOPs": flops / t / 1e12,
+                            "frac_of_fp32_vector_peak": flops / t / 1e12 / 157.3,
+                            "valu_kernel_s": tv, "valu_kernel_pred_per_s": M / tv}
     print("C4", json.dumps(res["C4_single_gpu"]), flush=True)
 
     os.makedirs("gpurun_out", exist_ok=True)
