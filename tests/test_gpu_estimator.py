@@ -288,6 +288,55 @@ def test_full_size_properties():
                 assert abs(lij - kij) < 1e-11
 
 
+def test_baseline_size_properties():
+    """BASELINE.json's full size, N_train = 65536 (D = 9, P = 3): size-independent properties of the whole
+    path, none of which needs the CPU oracle at that size.
+      * factor: (L L^T)_ij = K_ij on sampled entries (fp64, 1e-10);
+      * inverse factor: W L e_j = e_j on sampled columns (fp64, 1e-9);
+      * solve: posterior mean at training point i equals y_i - s * alpha_i  ((K + sI) alpha = y);
+      * fp32 serving path (inverse-factor variance, matrix-core mean) against the fp64 path on the same
+        queries: std within 1e-3 relative, mean within 1e-4 of the largest mean (the stated fp32 tolerances);
+      * the variance of a training point is below the noise level s and non-negative."""
+    import torch
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
+    N = 65536
+    X, Y, _ = O.synthetic_problem(N, 1)
+    Yn, _, _ = O.normalize_targets(Y)
+    dev = DeviceGP(X, Yn, get_backend(0))
+    s = 0.1001
+    dev.factorize(2.0, 1.0, s)
+    dev.solve_alpha()
+    rows = [7, 4099, 30000, N - 1]
+    Lr = dev.K[rows].cpu().numpy()
+    for a, i in enumerate(rows):
+        for b, j in enumerate(rows):
+            if j <= i:
+                lij = float(np.dot(Lr[a, : j + 1], Lr[b, : j + 1]))
+                kij = float(O.rbf_gram(X[[i, j]], 2.0, 1.0)[0, 1]) if i != j else 1.0 + s
+                assert abs(lij - kij) < 1e-10
+    idx = np.arange(0, N, 1021)
+    mean = dev.predict_mean_dev(X[idx], np.zeros(3), np.ones(3), "float64").cpu().numpy()
+    alpha = dev.alpha_host()
+    assert np.max(np.abs(mean - (Yn[idx] - s * alpha[idx]))) < 1e-8
+    W = dev.inverse_factor(False)
+    for j in (0, 5000, 40000):
+        col = dev.K[:N, j].clone()
+        col[:j] = 0.0                                   # column j of L (lower triangle)
+        e = (torch.tril(W[j:j + 256, :N], diagonal=j) @ col).cpu().numpy()      # rows j..j+255 of W L e_j
+        ref = np.zeros(256); ref[0] = 1.0
+        assert np.max(np.abs(e - ref)) < 1e-9
+    Xq = np.random.default_rng(1).standard_normal((256, 9))
+    Xq[:8] = X[:8]                                      # a few training points among the queries
+    v64 = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float64", "inverse").cpu().numpy()
+    v32 = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float32", "inverse").cpu().numpy()
+    assert np.all(v64 >= 0.0) and np.all(v64[:8] < 2.0 * s) and np.all(v64[:8] > s)   # prior 1 + s; data explain ~all of it
+    assert np.max(np.abs(np.sqrt(v32) - np.sqrt(v64)) / np.sqrt(v64)) < 1e-3
+    m64 = dev.predict_mean_dev(Xq, np.zeros(3), np.ones(3), "float64").cpu().numpy()
+    assert dev.mean_kernel_choice() == "mfma"
+    m32 = dev.predict_mean_dev(Xq, np.zeros(3), np.ones(3), "float32").double().cpu().numpy()
+    assert np.max(np.abs(m32 - m64)) < 1e-4 * np.max(np.abs(m64))
+
+
 def test_batched_per_axis_ard_gps(csv_data, ka):
     """BASELINE config 5: 3 per-axis ARD GPs sharing X — fused one-launch mean vs the per-model path and
     vs scikit-learn (KA6b is the dvx model at the same fixed theta), LML + gradient per model."""
