@@ -60,22 +60,24 @@ def test_gemm_tiles_random_and_lower(be):
     be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(Ad), k, _p(Ad), k, _p(Cd), m, m, m, k, -1.0, 1.0, 1))
     out = Cd.cpu().numpy()
     ref = C0 - A @ A.T
-    # > 512 tiles: exercises the super-tile mapping, full and lower-triangular
-    m2, k2 = 3200, 128
-    A2 = rng.standard_normal((m2, k2))
-    A2d = be.upload(A2)
-    for lower in (0, 1):
-        C2d = be.upload(np.zeros((m2, m2)))
-        be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(A2d), k2, _p(A2d), k2, _p(C2d), m2, m2, m2, k2, 1.0,
-                                       0.0, lower))
-        o2 = C2d.cpu().numpy()
-        r2 = A2 @ A2.T
-        if lower:
-            msk = np.kron(np.tril(np.ones((25, 25))), np.ones((128, 128))).astype(bool)
-            tri2 = np.tril(np.ones((m2, m2), dtype=bool))
-            assert relerr(o2[tri2], r2[tri2]) < 1e-13 and not o2[~msk].any()
-        else:
-            assert relerr(o2, r2) < 1e-13
+    # > 512 tiles: exercises the super-tile mapping, full and lower-triangular (3200: direct lower grid;
+    # 4096 / 4224: the folded-triangle mapping with an even / odd number of tile rows)
+    for m2 in (3200, 4096, 4224):
+        k2 = 128
+        A2 = rng.standard_normal((m2, k2))
+        A2d = be.upload(A2)
+        for lower in (0, 1):
+            C2d = be.upload(np.zeros((m2, m2)))
+            be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(A2d), k2, _p(A2d), k2, _p(C2d), m2, m2, m2, k2,
+                                           1.0, 0.0, lower))
+            o2 = C2d.cpu().numpy()
+            r2 = A2 @ A2.T
+            if lower:
+                msk = np.kron(np.tril(np.ones((m2 // 128, m2 // 128))), np.ones((128, 128))).astype(bool)
+                tri2 = np.tril(np.ones((m2, m2), dtype=bool))
+                assert relerr(o2[tri2], r2[tri2]) < 1e-13 and not o2[~msk].any()
+            else:
+                assert relerr(o2, r2) < 1e-13
     # short-and-wide / tall-and-narrow grids (adaptive super-tile shape)
     for (mm, nn) in ((256, 40 * 128), (40 * 128, 384)):
         Aa, Bb = rng.standard_normal((mm, 64)), rng.standard_normal((nn, 64))

@@ -40,6 +40,11 @@ for dt, tdt, code in (("f32", torch.float32, _lib.GPK_F32), ("f64", torch.float6
         be.check(be.lib.gpk_gemm_tiles(be.h, code, 0, 1, C.c_void_p(A.data_ptr()), k, C.c_void_p(B.data_ptr()), k,
                                        C.c_void_p(Cm.data_ptr()), n, m, n, k, 1.0, 0.0, 0))
     t = ev(run2, 5, 2); out["gemm_nt_" + dt + "_TF"] = round(2.0 * m * n * k / t / 1e12, 2)
+    def run3():
+        be.bind_stream()
+        be.check(be.lib.gpk_gemm_tiles(be.h, code, 0, 0, C.c_void_p(A.data_ptr()), k, C.c_void_p(A.data_ptr()), k,
+                                       C.c_void_p(Cm.data_ptr()), n, m, m, k, -1.0, 1.0, 1))
+    t = ev(run3, 5, 2); out["syrk_" + dt + "_TF"] = round(1.0 * m * (m + 128) * k / t / 1e12, 2)
     del A, B, Cm
 N = int(os.environ.get("EXP_N", "32768")); M = 10000
 rng = np.random.default_rng(0); X = rng.standard_normal((N, 9)); Y = np.sin(X @ rng.standard_normal((9, 3)))

@@ -26,6 +26,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_GEMM_WM_F64")) h->gemm_wm_f64 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
+  if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
   *out = h;
   return GPK_OK;
 }

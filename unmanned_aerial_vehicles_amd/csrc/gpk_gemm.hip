@@ -471,6 +471,9 @@ int gpk_gemm_tile(gpk_handle h, const GemmArgs& g) {
 
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   const int bk = dtype == GPK_F64 ? 16 : 32;
+  if (h->gemm_log)   // GPK_GEMM_LOG=1: one line per launch, in launch order (joined with a rocprofv3 kernel trace)
+    fprintf(stderr, "GPKGEMM %d %d %d %d ta%d tb%d lo%d kb %d %d %d ke %d %d %d\n", dtype, g.m, g.n, g.k, g.ta, g.tb,
+            g.lower_only, g.kb0, g.kb_row, g.kb_col, g.ke0, g.ke_row, g.ke_col);
   GPK_REQUIRE(h, g.m > 0 && g.n > 0 && g.m % 128 == 0 && g.n % 128 == 0, "gemm: m, n must be multiples of 128");
   GPK_REQUIRE(h, g.k >= 0 && g.k % bk == 0, "gemm: k must be a multiple of the k-tile");
   GPK_REQUIRE(h, g.kb0 % bk == 0 && g.kb_row % bk == 0 && g.kb_col % bk == 0 && (g.ke0 < 0 || g.ke0 % bk == 0) &&
