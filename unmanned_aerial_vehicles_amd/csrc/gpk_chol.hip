@@ -30,6 +30,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int LSA = 130;   // LDS row stride of the 128 x 128 image
 constexpr int LSW = 18;    // row stride of the 16 x 16 diagonal inverses
 
+// order the LDS traffic of ONE wave (its ds operations execute in order; this only stops the compiler from
+// moving them across)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool FACTOR>
 __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long long lda, int row0,
                                                    int* __restrict__ info0, double* __restrict__ W0,
@@ -40,6 +47,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
   int* __restrict__ info = info0 + blockIdx.x;
   __shared__ __attribute__((aligned(16))) double a[NB * LSA];
   __shared__ __attribute__((aligned(16))) double wd[8 * 16 * LSW];   // wd[b][r][c] = W_bb[c][r]
+  __shared__ double colbuf[32];    // P2: current column / 1 / L_cc (0..15) and L_cc (16..31) of the diagonal block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   for (int e = tid; e < NB * NB; e += 256) {
@@ -70,29 +78,61 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
         }
         __syncthreads();
       }
-      // ---- P2: unblocked factorisation of the 16 x 16 diagonal block (columns stay unscaled)
-      {
-        const int i = tid >> 4, k = tid & 15;
+      // ---- P2: unblocked factorisation of the 16 x 16 diagonal block by ONE wave, its lower triangle in
+      // registers (lane = (row i, column group kq): columns kq, kq + 4, kq + 8, kq + 12).  Each of the 16
+      // column steps publishes the current column through a 16-entry LDS buffer; a wave's LDS operations
+      // complete in order, so no workgroup barrier is needed inside the loop.  Columns stay unscaled
+      // (a_ik -= a_ic a_kc / d) until the final scaling by 1 / sqrt(pivot), which also leaves the
+      // reciprocal diagonal for P3.
+      if (wave == 0) {
+        const int i = lane & 15, kq = lane >> 4;
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = a[(c0 + i) * LSA + c0 + kq + 4 * r];
+#pragma unroll
         for (int c = 0; c < 16; ++c) {
-          double d = a[(c0 + c) * LSA + c0 + c];
+          if (kq == (c & 3)) colbuf[i] = v[c >> 2];
+          wave_lds_sync();
+          // all six values in one batch of LDS reads and branch-free selects below (with the updates under
+          // branches the compiler sinks each read into its branch: six serialised LDS round trips per step)
+          double d = colbuf[c];
+          const double ci = colbuf[i];
+          double ck[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ck[r] = colbuf[kq + 4 * r];
           if (!(d > 0.0)) {                      // not positive definite (or NaN): record, stay finite
-            if (tid == 0) atomicCAS(info, 0, row0 + c0 + c + 1);
+            if (lane == 0) atomicCAS(info, 0, row0 + c0 + c + 1);
             d = 1.0;
           }
-          if (i > c && k > c && k <= i)
-            a[(c0 + i) * LSA + c0 + k] -= a[(c0 + i) * LSA + c0 + c] * a[(c0 + k) * LSA + c0 + c] / d;
-          __syncthreads();
+          // 1 / d by v_rcp_f64 + two Newton steps (error ~1e-16): the division is on the loop's critical path
+          double rd = __builtin_amdgcn_rcp(d);
+          rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+          rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+          const double f = ci * rd;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = kq + 4 * r;
+            const double u = __builtin_fma(-f, ck[r], v[r]);
+            v[r] = (i > c && k > c && k <= i) ? u : v[r];
+          }
+          wave_lds_sync();
         }
-        double p = a[(c0 + k) * LSA + c0 + k];
-        if (!(p > 0.0)) p = 1.0;
-        const double v = a[(c0 + i) * LSA + c0 + k];
-        __syncthreads();
-        if (k <= i) {
-          const double sq = __builtin_sqrt(p);
-          a[(c0 + i) * LSA + c0 + k] = (i == k) ? sq : v / sq;
+        if (kq == (i & 3)) {
+          double pv = v[i >> 2];
+          if (!(pv > 0.0)) pv = 1.0;
+          const double sq = __builtin_sqrt(pv);
+          colbuf[i] = 1.0 / sq;
+          colbuf[16 + i] = sq;
         }
-        __syncthreads();
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = kq + 4 * r;
+          if (k < i) a[(c0 + i) * LSA + c0 + k] = v[r] * colbuf[k];
+          else if (k == i) a[(c0 + i) * LSA + c0 + k] = colbuf[16 + i];
+        }
       }
+      __syncthreads();
     }
     // ---- P3: panel rows x L_jj^T = a (threads 0..111) and identity rows -> W_jj^T (threads 112..127)
     if (tid < 128) {
@@ -104,7 +144,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
         for (int c = 0; c < 16; ++c) x[c] = ident ? ((c == row) ? 1.0 : 0.0) : a[row * LSA + c0 + c];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          x[c] = x[c] / a[(c0 + c) * LSA + c0 + c];
+          x[c] = FACTOR ? x[c] * colbuf[c] : x[c] / a[(c0 + c) * LSA + c0 + c];
 #pragma unroll
           for (int c2 = c + 1; c2 < 16; ++c2) x[c2] = __builtin_fma(-x[c], a[(c0 + c2) * LSA + c0 + c], x[c2]);
         }
