@@ -132,6 +132,21 @@ int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, 
                      int P, const double* ls, double sf2, const double* y_mean,
                      const double* y_std, const void* Xq, int64_t M, void* mean);
 
+/* One-call serving for the control loop (fp64): host queries in, host posterior mean (and variance) out.
+ * Copies Xq (host, M x D) through a pinned staging block owned by the handle, runs gpk_predict_mean and -
+ * when var_host != NULL - gpk_predict_var_inv with the explicit inverse factor W (dev Np x ldw, gpk_trtri),
+ * copies the results back and synchronises the handle's stream: one call and one synchronisation per MPC
+ * step instead of an upload, two launch chains and two downloads driven from the host language.
+ * mean_host: M x P (un-normalised with y_mean / y_std); var_host: M (normalised-target units: the caller
+ * scales by y_std^2), clipped below at floor_.  1 <= M <= GPK_HOST_MAX_M.
+ * Replaces: the per-call path of src/px4/simple_gp.py:187-201 (predict_residual) and the 25-call loop of
+ * src/px4/mpc.py:1490-1506; sklearn/_gpr.py:441-494.                                                     */
+#define GPK_HOST_MAX_M 4096
+int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P,
+                     const double* ls, double sf2, const double* y_mean, const double* y_std,
+                     const double* W, int64_t Np, int64_t ldw, double kss, double floor_,
+                     const double* Xq_host, int64_t M, double* mean_host, double* var_host);
+
 /* K4 on the matrix cores, fp32 only: the same posterior mean as gpk_predict_mean(GPK_F32, ...), with the
  * pairwise squared distances of 32 x 32 (query, training point) blocks formed by v_mfma_f32_32x32x2_f32
  * from centred, scaled coordinates (|a|^2 + |b|^2 - 2 a.b: one augmented dot product of length D + 1) and

@@ -288,6 +288,31 @@ def test_full_size_properties():
                 assert abs(lij - kij) < 1e-11
 
 
+def test_one_call_host_path(csv_data):
+    """Small batches (the control loop's 1..25 rows) go through gpk_predict_host (one C call, pinned staging, one
+    synchronisation); larger ones through device tensors.  Same numbers to fp64 round-off, and the path choice
+    is what the estimator documents."""
+    from unmanned_aerial_vehicles_amd import GaussianProcessRegressor, RBF, WhiteKernel
+    X, Y = csv_data["X10"], csv_data["Y6"]
+    gp = GaussianProcessRegressor(kernel=RBF(0.5) + WhiteKernel(0.1), alpha=1e-4, normalize_y=True, optimizer=None).fit(X, Y)
+    dev = gp._dev
+    assert dev.host_path_ok(1, True) and dev.host_path_ok(256, True) and not dev.host_path_ok(257, True)
+    Xq = csv_data["Xq10"]
+    big_m, big_s = gp.predict(np.vstack([Xq] * 5)[:300], return_std=True)        # 300 rows: device-tensor path
+    for M in (1, 25, 64):
+        m, s = gp.predict(Xq[:M], return_std=True)                               # host path
+        assert m.shape == (M, 6) and s.shape == (M, 6)
+        assert np.max(np.abs(m - big_m[:M])) < 1e-12 and np.max(np.abs(s - big_s[:M]) / big_s[:M]) < 1e-9
+        m_only = gp.predict(Xq[:M])
+        assert np.array_equal(m_only, m)
+    # direct call: variance in normalised units, clipped at the floor
+    mean, var = dev.predict_host(Xq[:7], gp._y_train_mean, gp._y_train_std, 1.1, 0.0)
+    vd = dev.predict_var_dev(Xq[:7], 1.1, 0.0, "float64", "inverse").cpu().numpy()
+    assert np.max(np.abs(var - vd)) < 1e-12 and np.all(var >= 0.0)
+    with pytest.raises(ValueError):
+        dev.predict_host(Xq[:3, :5], gp._y_train_mean, gp._y_train_std)
+
+
 def test_baseline_size_properties():
     """BASELINE.json's full size, N_train = 65536 (D = 9, P = 3): size-independent properties of the whole
     path, none of which needs the CPU oracle at that size.

@@ -15,6 +15,7 @@ from ._build import LIB_PATH
 GPK_F32, GPK_F64 = 0, 1
 GPK_OK, GPK_NOT_PD, GPK_BAD_ARG, GPK_HIP_ERROR = 0, 1, 2, 3
 GPK_TILE, GPK_MAX_D, GPK_MAX_P = 128, 64, 16
+GPK_HOST_MAX_M = 4096
 
 _vp, _i64, _int, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
 _dp = C.POINTER(C.c_double)
@@ -42,6 +43,8 @@ SIGNATURES = {
     "gpk_trsm_lower_left": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _vp, _i64, _i64]),
     "gpk_colsumsq": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp]),
     "gpk_predict_mean": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _vp]),
+    "gpk_predict_host": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _vp, _i64, _i64, _dbl, _dbl, _dp,
+                                _i64, _dp, _dp]),
     "gpk_predict_mean_mfma": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_mean_multi": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,

@@ -39,6 +39,8 @@ extern "C" void gpk_destroy(gpk_handle h) {
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_small) (void)hipFree(h->d_small);
   if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->serve_dev) (void)hipFree(h->serve_dev);
+  if (h->serve_host) (void)hipHostFree(h->serve_host);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -138,6 +140,56 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   GPK_TRY(gpk_gemm(h, dtype, g));
   GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
   return gpk_var_finalize(h, var, M, kss, floor_, var);
+}
+
+// ---- one-call serving for the control loop: host queries in, host mean / variance out ------------------
+extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P,
+                                const double* ls, double sf2, const double* y_mean, const double* y_std,
+                                const double* W, int64_t Np, int64_t ldw, double kss, double floor_,
+                                const double* Xq_host, int64_t M, double* mean_host, double* var_host) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && alpha && ls && y_mean && y_std && Xq_host && mean_host, "predict_host: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && M <= GPK_HOST_MAX_M, "predict_host: M must be in [1, GPK_HOST_MAX_M]");
+  GPK_REQUIRE(h, !var_host || (W && Np == gpk_padded(N) && ldw >= Np), "predict_host: variance needs the inverse factor");
+  GPK_REQUIRE(h, h->batch == 1, "predict_host: not available in batched mode");
+  const int64_t Mp = gpk_padded(M);
+  // pinned host block [Xq | pad][mean | var | pad]; device block [Xq | pad][K* work panel of the variance GEMM]
+  const size_t nq = ((size_t)M * D + 15) & ~(size_t)15, nm = (size_t)M * P, nv = (size_t)M;
+  const size_t nout_pad = (nm + nv + 15) & ~(size_t)15;
+  const size_t host_need = (nq + nout_pad) * sizeof(double);
+  const size_t dev_need = (nq + (var_host ? (size_t)Mp * Np : 0)) * sizeof(double);
+  if (host_need > h->serve_host_bytes || dev_need > h->serve_dev_bytes) {
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+    if (host_need > h->serve_host_bytes) {
+      if (h->serve_host) GPK_CHECK_HIP(h, hipHostFree(h->serve_host));
+      h->serve_host = nullptr; h->serve_host_bytes = 0;
+      const size_t want = (host_need + 65535) & ~(size_t)65535;
+      GPK_CHECK_HIP(h, hipHostMalloc(&h->serve_host, want, hipHostMallocMapped | hipHostMallocCoherent));
+      h->serve_host_bytes = want;
+    }
+    if (dev_need > h->serve_dev_bytes) {
+      if (h->serve_dev) GPK_CHECK_HIP(h, hipFree(h->serve_dev));
+      h->serve_dev = nullptr; h->serve_dev_bytes = 0;
+      const size_t want = (dev_need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+      GPK_CHECK_HIP(h, hipMalloc(&h->serve_dev, want));
+      h->serve_dev_bytes = want;
+    }
+  }
+  // The staging block is pinned, coherent host memory mapped into the device's address space: the queries go to
+  // HBM with one async copy (every workgroup re-reads them), mean / variance are written by the kernels straight
+  // into the pinned block (a few hundred bytes over PCIe): no download command, one stream synchronisation.
+  double* hq = (double*)h->serve_host;
+  double* hout = hq + nq;                      // [mean | var]
+  double* dq = (double*)h->serve_dev;
+  double* dwork = dq + nq;
+  memcpy(hq, Xq_host, (size_t)M * D * sizeof(double));
+  GPK_CHECK_HIP(h, hipMemcpyAsync(dq, hq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  GPK_TRY(gpk_predict_mean(h, GPK_F64, X, alpha, N, D, P, ls, sf2, y_mean, y_std, dq, M, hout));
+  if (var_host) GPK_TRY(gpk_predict_var_inv(h, GPK_F64, X, N, D, ls, sf2, W, Np, ldw, dq, M, kss, floor_, dwork, hout + nm));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  memcpy(mean_host, hout, nm * sizeof(double));
+  if (var_host) memcpy(var_host, hout + nm, nv * sizeof(double));
+  return GPK_OK;
 }
 
 extern "C" int gpk_gemm_tiles(gpk_handle h, int dtype, int ta, int tb, const void* A, int64_t lda, const void* B,

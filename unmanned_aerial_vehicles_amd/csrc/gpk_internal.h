@@ -22,6 +22,11 @@ struct gpk_context {
   int* d_info = nullptr;        // device int for potrf pivot failures
   double* d_small = nullptr;    // 4 KiB device doubles for reductions
   double* h_small = nullptr;    // pinned host mirror
+  // staging of gpk_predict_host: device block [Xq | mean | var | K* work] and its pinned host mirror [Xq | mean | var]
+  void* serve_dev = nullptr;
+  size_t serve_dev_bytes = 0;
+  void* serve_host = nullptr;
+  size_t serve_host_bytes = 0;
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 128;

@@ -342,6 +342,41 @@ class DeviceGP:
                                              _p(out)))
         return out
 
+    # queries per call up to which predict() goes through the one-call host path (gpk_predict_host)
+    HOST_PATH_MAX_M = 256
+
+    def host_path_ok(self, M, want_var):
+        """The fp64 one-call serving path applies to small batches; its variance needs the fp64 inverse factor,
+        which is at hand (or cheap to form) up to INVERSE_EAGER_NP."""
+        if not (1 <= M <= self.HOST_PATH_MAX_M and self.D <= 16):
+            return False
+        return (not want_var) or ("f64" in self._Winv) or self.Np <= self.INVERSE_EAGER_NP
+
+    def predict_host(self, Xq, y_mean, y_std, kss=None, floor=0.0):
+        """One C call per batch: host queries (M, D) float64 -> (mean (M, P), var (M,) or None) as NumPy arrays
+        (mean un-normalised, var in normalised-target units); kss=None skips the variance."""
+        assert self.factored or kss is None
+        Xq = np.ascontiguousarray(Xq, dtype=np.float64)
+        M = Xq.shape[0]
+        if Xq.ndim != 2 or Xq.shape[1] != self.D:
+            raise ValueError(f"queries must be (M, {self.D})")
+        mean = np.empty((M, self.P))
+        var = np.empty((M,)) if kss is not None else None
+        ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
+        ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
+        W = self.inverse_factor(False) if kss is not None else None
+        be = self.be
+        dp = _lib._dp
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_predict_host(be.h, _p(self.X), _p(self.alpha), self.N, self.D, self.P,
+                                             self.ls.ctypes.data_as(dp), self.sf2, ym.ctypes.data_as(dp),
+                                             ys.ctypes.data_as(dp), _p(W) if W is not None else None, self.Np, self.Np,
+                                             float(kss) if kss is not None else 0.0, float(floor),
+                                             Xq.ctypes.data_as(dp), M, mean.ctypes.data_as(dp),
+                                             var.ctypes.data_as(dp) if var is not None else None))
+        return mean, var
+
     def inverse_factor(self, f32):
         """W = L^-1 (lower, by tiles) on the fp64 MFMA; kept as fp64 or as an fp32 copy.  One-off
         N^3/3 flops per factorisation; makes every later variance call a single GEMM launch."""

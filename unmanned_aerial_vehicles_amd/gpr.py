@@ -194,6 +194,20 @@ class GaussianProcessRegressor:
             return mean
         self._ensure_device()
         dev = self._dev
+        if (self.predict_dtype != "float32" and self.var_method in ("auto", "inverse")
+                and dev.host_path_ok(X.shape[0], return_std)):
+            # small batches (the control loop's 1..25 rows): one C call, one synchronisation
+            kss = None
+            if return_std:
+                comp = self.kernel_.components()
+                kss = comp.sf2 + (comp.noise or 0.0)
+            mean, var = dev.predict_host(X, self._y_train_mean, self._y_train_std, kss, 0.0)
+            if not return_std:
+                return mean[:, 0] if mean.shape[1] == 1 else mean
+            var = np.outer(var, self._y_train_std ** 2)
+            if mean.shape[1] == 1:
+                mean, var = mean[:, 0], var[:, 0]
+            return mean, np.sqrt(var)
         import torch
         q = dev.be.upload(X, torch.float32 if self.predict_dtype == "float32" else torch.float64)
         mean_d = dev.predict_mean_dev(q, self._y_train_mean, self._y_train_std, self.predict_dtype).double()

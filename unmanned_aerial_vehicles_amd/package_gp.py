@@ -121,6 +121,10 @@ class GaussianProcess:
             return prior
         try:
             dev, sf2 = model
+            if self.predict_dtype != "float32" and dev.host_path_ok(len(X_test), True):
+                # small batches: one C call and one synchronisation (gpk_predict_host)
+                mean, var = dev.predict_host(X_test, np.zeros(dev.P), np.ones(dev.P), sf2, 1e-10)
+                return mean, np.tile(var.reshape(-1, 1), (1, self.output_dim))
             mean = dev.predict_mean_dev(X_test, np.zeros(dev.P), np.ones(dev.P), self.predict_dtype)
             var = dev.predict_var_dev(X_test, sf2, 1e-10, self.predict_dtype)
             mean = mean.double().cpu().numpy()
