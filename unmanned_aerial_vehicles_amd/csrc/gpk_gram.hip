@@ -365,19 +365,17 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(const T* __restrict__
   for (long long jb = n0; jb < n1; jb += PM_TJ) {
     const int nj = (int)min((long long)PM_TJ, n1 - jb);
     __syncthreads();
-    // stage [x/ls | 0.. | alpha | 0..] for PM_TJ rows (rows beyond nj are zero-filled: alpha = 0)
-    for (int e = tid; e < PM_TJ * (DD + PP); e += 256) {
+    // stage [x/ls | 0.. | alpha | 0..] for the nj <= PM_TJ rows of this round
+    for (int e = tid; e < nj * (DD + PP); e += 256) {
       const int j = e / (DD + PP), c = e - j * (DD + PP);
       T v = T(0);
-      if (j < nj) {
-        if (c < DD) { if (c < D) v = X[(jb + j) * D + c] / T(ls.v[c]); }
-        else if (c - DD < P) v = alpha[(jb + j) * P + (c - DD)];
-      }
+      if (c < DD) { if (c < D) v = X[(jb + j) * D + c] / T(ls.v[c]); }
+      else if (c - DD < P) v = alpha[(jb + j) * P + (c - DD)];
       rows[j * PM_RS + (c < DD ? c : PM_DMAX + (c - DD))] = v;
     }
     __syncthreads();
 #pragma unroll 2
-    for (int j = 0; j < PM_TJ; ++j) {
+    for (int j = 0; j < nj; ++j) {
       const Q4* row = reinterpret_cast<const Q4*>(rows + j * PM_RS);
       T xt[DD], al[PP];
 #pragma unroll
@@ -681,14 +679,17 @@ extern "C" int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const vo
   Ls16 l16;
   for (int d = 0; d < 16; ++d) l16.v[d] = l.v[d];
   const int64_t nqb = (M + 256 * PM_QPT - 1) / (256 * PM_QPT);
-  // split the training set so that the grid has >= ~2048 workgroups (8 per CU)
+  // split the training set so that the grid has >= ~2048 workgroups (8 per CU); a handful of queries against
+  // a small training set (the control loop: 1..25 rows at N ~ 1000) is pure latency - a thread walks its
+  // chunk serially - so those get chunks of 32 rows instead of 128
+  const int64_t gran = (M <= 512 && N <= 16384) ? 32 : PM_TJ;
   int64_t S = (2048 + nqb - 1) / nqb;
-  const int64_t maxS = (N + PM_TJ - 1) / PM_TJ;
+  const int64_t maxS = (N + gran - 1) / gran;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
   if (S > 65535) S = 65535;
   int64_t chunk = (N + S - 1) / S;
-  chunk = (chunk + PM_TJ - 1) / PM_TJ * PM_TJ;
+  chunk = (chunk + gran - 1) / gran * gran;
   S = (N + chunk - 1) / chunk;
   const size_t es = dtype == GPK_F64 ? 8 : 4;
   void* partial = nullptr;
