@@ -17,10 +17,6 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-#ifndef GPK_PIPE
-#define GPK_PIPE 0
-#endif
-
 constexpr int LDS_N_STRIDE = 144;    // bytes per row of a k-contiguous tile (128 + 16 pad)
 
 template <typename T> struct Cfg;
@@ -93,13 +89,13 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const V16 (&r)[TS
 
 // ---- fp64: AB x NB blocks of 16x16x4 per wave.  Within a k-tile the k index is permuted so that a lane's
 // four k values (4 kq .. 4 kq + 3) are contiguous: two ds_read_b128 per block row for k-contiguous images.
-template <bool TA, bool TB, int AB, int NB, int TS, int PART = 0, int NPARTS = 1>
+template <bool TA, bool TB, int AB, int NB, int TS>
 __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int row_w, int col_w, int lane,
                                              d4 (&acc)[AB][NB]) {
   const int r = lane & 15, kq = lane >> 4;
   constexpr int RS = (TS + 4) * 8;
 #pragma unroll
-  for (int hh = 2 * PART / NPARTS; hh < 2 * (PART + 1) / NPARTS; ++hh) {
+  for (int hh = 0; hh < 2; ++hh) {
     double af[AB][2], bf[NB][2];
 #pragma unroll
     for (int a = 0; a < AB; ++a) {
@@ -135,13 +131,13 @@ __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int
 
 // ---- fp32: AB x NB blocks of 32x32x2 per wave; a lane's sixteen k values (16 kq .. 16 kq + 15) are
 // contiguous: four ds_read_b128 per block row.
-template <bool TA, bool TB, int AB, int NB, int TS, int PART = 0, int NPARTS = 1>
+template <bool TA, bool TB, int AB, int NB, int TS>
 __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int row_w, int col_w, int lane,
                                              f16v (&acc)[AB][NB]) {
   const int r = lane & 31, kq = lane >> 5;
   constexpr int RS = (TS + 4) * 4;
 #pragma unroll
-  for (int q = 4 * PART / NPARTS; q < 4 * (PART + 1) / NPARTS; ++q) {  // 4 groups of 4 k-steps
+  for (int q = 0; q < 4; ++q) {  // 4 groups of 4 k-steps
     float af[AB][4], bf[NB][4];
 #pragma unroll
     for (int a = 0; a < AB; ++a) {
@@ -370,6 +366,9 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     // registers hold k-tile kt+1 (fetched during iteration kt-1's MFMAs); they are written to the
     // idle LDS buffer, the fetch of k-tile kt+2 is issued, and the MFMAs of k-tile kt run while it
     // is in flight.  One barrier per k-tile; tile indices are clamped so the body is branch-free.
+    // (Measured and not kept - DESIGN.md: fetch pinned to the top or the middle of the MFMAs with
+    // sched_barrier, s_setprio around the MFMAs: equal or slower on the throughput shapes; 2 or 4 k-tiles per
+    // iteration for the 64-tile small-grid configuration: no gain.)
     V16 ra[TS * 8 / NT], rb[TS * 8 / NT];
     load_tile<T, TA, NT, TS>(A, p.lda, row0, kb, tid, ra);
     load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb, tid, rb);
@@ -388,29 +387,9 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
       const int kn = min(kt + 2, nkt - 1);
       const char* la = lds + cur * 2 * LDS_OP_BYTES;
       const char* lb = la + LDS_OP_BYTES;
-#if GPK_PIPE == 0 || GPK_PIPE == 3
       load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + kn * BK, tid, ra);
       load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + kn * BK, tid, rb);
-      if (GPK_PIPE == 3) __builtin_amdgcn_s_setprio(1);
       compute_tile<TA, TB, AB, NB, TS>(la, lb, row_w, col_w, lane, acc);
-      if (GPK_PIPE == 3) __builtin_amdgcn_s_setprio(0);
-#elif GPK_PIPE == 1 || GPK_PIPE == 4
-      load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + kn * BK, tid, ra);
-      load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + kn * BK, tid, rb);
-      __builtin_amdgcn_sched_barrier(0);
-      if (GPK_PIPE == 4) __builtin_amdgcn_s_setprio(1);
-      compute_tile<TA, TB, AB, NB, TS>(la, lb, row_w, col_w, lane, acc);
-      if (GPK_PIPE == 4) __builtin_amdgcn_s_setprio(0);
-#else
-      if (GPK_PIPE == 5) __builtin_amdgcn_s_setprio(1);
-      compute_tile<TA, TB, AB, NB, TS, 0, 2>(la, lb, row_w, col_w, lane, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + kn * BK, tid, ra);
-      load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + kn * BK, tid, rb);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_tile<TA, TB, AB, NB, TS, 1, 2>(la, lb, row_w, col_w, lane, acc);
-      if (GPK_PIPE == 5) __builtin_amdgcn_s_setprio(0);
-#endif
       __syncthreads();
     }
   }
