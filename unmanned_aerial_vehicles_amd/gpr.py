@@ -111,8 +111,11 @@ class GaussianProcessRegressor:
             self.kernel_.theta = optima[int(np.argmin(vals))][0]
             self.log_marginal_likelihood_value_ = -float(np.min(vals))
             self._dev.release_grad_buffers()
+            lml_from_final_factor = False
         else:
-            self.log_marginal_likelihood_value_ = self._lml_on_device(self.kernel_.theta, eval_gradient=False)
+            # fixed theta: the reference evaluates the LML (one Cholesky) and then factorises again for
+            # prediction (_gpr.py:339-349); here the one factorisation below serves both
+            lml_from_final_factor = True
 
         # final factorisation at the selected theta (_gpr.py:343-364); not-PD raises here
         comp = self.kernel_.components()
@@ -123,6 +126,10 @@ class GaussianProcessRegressor:
                         "increasing the 'alpha' parameter of your GaussianProcessRegressor estimator.",) + exc.args
             raise
         self._dev.solve_alpha()
+        if lml_from_final_factor:
+            logdet_half, quad = self._dev.lml_terms()
+            self.log_marginal_likelihood_value_ = float(
+                np.sum(-0.5 * quad - logdet_half - 0.5 * self._dev.N * LOG_2PI))
         self._alpha_host = None
         self._L_host = None
         return self
