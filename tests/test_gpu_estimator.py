@@ -403,6 +403,36 @@ def test_batched_per_axis_ard_gps(csv_data, ka):
     assert relerr(bg2.predict(Xq)[:, 1], ref1) < 1e-12
 
 
+def test_batched_large_fp32_batches_use_matrix_core_kernel():
+    """BatchedARDGP.predict_mean_dev: large fp32 batches go model by model through the matrix-core mean kernel,
+    small ones through the single fused launch; both agree with the fp64 per-model means."""
+    from unmanned_aerial_vehicles_amd import BatchedARDGP
+    rng = np.random.default_rng(3)
+    N, D, B = 1500, 9, 3
+    X = rng.standard_normal((N, D))
+    Y = np.sin(X @ rng.standard_normal((D, B))) + 0.05 * rng.standard_normal((N, B))
+    ls = np.stack([np.full(D, 1.5) * (1.0 + 0.1 * b + 0.05 * np.arange(D)) for b in range(B)])
+    bg = BatchedARDGP(length_scale=ls[0], noise_level=0.05, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, Y)
+    for b, m in enumerate(bg.models):                    # distinct length-scales per model
+        k = m.kernel_
+        th = k.theta.copy(); th[:D] = np.log(ls[b]); k.theta = th
+        m._refactor()
+    bg._fused = None
+    Xq = rng.standard_normal((2000, D))
+    ref = np.stack([m.predict(Xq) for m in bg.models], axis=1)           # fp64
+    bg.predict_dtype = "float32"
+    bg._fused = None
+    assert all(m._dev.mean_kernel_choice() == "mfma" for m in bg.models)
+    big = bg.predict_mean_dev(Xq).double().cpu().numpy()                 # 2000 >= MFMA_MIN_QUERIES: per-model MFMA
+    small = bg.predict_mean_dev(Xq[:100]).double().cpu().numpy()         # fused vector-ALU launch
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(big - ref)) < 1e-4 * scale and np.max(np.abs(small - ref[:100])) < 1e-4 * scale
+    thr, bg.MFMA_MIN_QUERIES = bg.MFMA_MIN_QUERIES, 1 << 40
+    fused = bg.predict_mean_dev(Xq).double().cpu().numpy()
+    bg.MFMA_MIN_QUERIES = thr
+    assert np.max(np.abs(fused - big)) < 1e-4 * scale and not np.array_equal(fused, big)   # two different kernels ran
+
+
 def test_offline_cli_round_trip(csv_data, ka, tmp_path):
     """train_offline CLI -> pickle + latest symlink -> evaluate_offline CLI -> metrics CSV."""
     from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP, evaluate_offline, train_offline

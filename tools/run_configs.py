@@ -160,12 +160,14 @@ def main():
         q5 = torch.as_tensor(Xq5, dtype=torch.float32, device=be.device)
         bg.predict_mean_dev(q5)
         t, _ = wall(lambda: bg.predict_mean_dev(q5), reps=5)
-        c5[f"N{N5}"]["fused_3gp_mean_10k_queries_ms"] = t * 1e3
-        for m in bg.models:
-            m.predict_dtype = "float32"
-        t, _ = wall(lambda: [m._dev.predict_mean_dev(q5, m._y_train_mean, m._y_train_std, "float32") for m in bg.models],
-                    reps=5)
-        c5[f"N{N5}"]["per_model_3gp_mean_10k_queries_ms"] = t * 1e3
+        c5[f"N{N5}"]["batched_3gp_mean_10k_queries_ms"] = t * 1e3       # what BatchedARDGP.predict_mean_dev does
+        thr, bg.MFMA_MIN_QUERIES = bg.MFMA_MIN_QUERIES, 1 << 40
+        t, _ = wall(lambda: bg.predict_mean_dev(q5), reps=5)            # forced: the fused vector-ALU kernel
+        bg.MFMA_MIN_QUERIES = thr
+        c5[f"N{N5}"]["fused_valu_3gp_mean_10k_queries_ms"] = t * 1e3
+        t, _ = wall(lambda: [m._dev.predict_mean_dev(q5, m._y_train_mean, m._y_train_std, "float32", "valu")
+                             for m in bg.models], reps=5)
+        c5[f"N{N5}"]["per_model_valu_3gp_mean_10k_queries_ms"] = t * 1e3
         del bg
         if have_skl and N5 == 4096:
             from sklearn.gaussian_process.kernels import ConstantKernel as SkC

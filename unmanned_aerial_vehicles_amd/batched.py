@@ -250,8 +250,11 @@ class BatchedARDGP:
             "ys": np.ascontiguousarray([m._y_train_std[0] for m in self.models], dtype=np.float64),
         }
 
+    MFMA_MIN_QUERIES = 1024      # below this the single fused launch wins on latency
+
     def predict_mean_dev(self, Xq):
-        """All B posterior means in one kernel launch; returns a (M, B) device tensor."""
+        """All B posterior means (one fused launch, or one matrix-core launch per model for large fp32
+        batches); returns a (M, B) device tensor."""
         import torch
         if self._fused is None:
             self._build_fused()
@@ -265,6 +268,12 @@ class BatchedARDGP:
         out = be.empty((M, B), f["tdt"])
         if M == 0:
             return out
+        if (f["code"] == _lib.GPK_F32 and M >= self.MFMA_MIN_QUERIES
+                and all(m._dev.mean_kernel_choice() == "mfma" for m in self.models)):
+            # large fp32 batches: one matrix-core launch per model (distances on the bf16 MFMA pipe) beats the
+            # fused vector-ALU kernel (0.115 vs 0.158 ms at N = 4096, 10 000 queries, B = 3)
+            cols = [m._dev.predict_mean_dev(q, m._y_train_mean, m._y_train_std, "float32", "mfma") for m in self.models]
+            return torch.cat(cols, dim=1)
         dp = _lib._dp
         with be.lock:
             be.bind_stream()
