@@ -38,33 +38,40 @@ struct KParams {
 };
 
 typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
+template <int V> struct IntC { static constexpr int value = V; };
 
 // ---- global -> registers -> LDS -------------------------------------------------------------------
 // An operand k-tile is TS rows x 128 bytes = TS * 8 chunks of 16 bytes, NP = TS * 8 / NT per thread.
+// The address of chunk p of k-tile kt is  ubase + kt * step + voff[p]:  voff (32-bit, per lane) is loop
+// invariant and ubase + kt * step is wave-uniform, so the loop body needs no vector address arithmetic
+// (global_load with a scalar base): the fp32 / fp64 MFMAs issue from the same vector lanes as ordinary VALU
+// instructions (measured: they do not overlap), so every v_mul / v_add in the loop costs MFMA time.
 template <typename T, bool TR, int NT, int TS>
-__device__ __forceinline__ void load_tile(const T* __restrict__ base, long long ld, int row0, int k0,
-                                          int tid, V16 (&r)[TS * 8 / NT]) {
+__device__ __forceinline__ void tile_offsets(long long ld, int tid, unsigned (&voff)[TS * 8 / NT]) {
   constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
   constexpr int NP = TS * 8 / NT;
   if constexpr (!TR) {
     // stored (rows x k): thread -> chunk c of row (tid >> 3) + (NT / 8) p
     const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const T* g = base + (long long)(row0 + rr + (NT / 8) * p) * ld + k0 + c * EPC;
-      r[p] = *reinterpret_cast<const V16*>(g);
-    }
+    for (int p = 0; p < NP; ++p) voff[p] = (unsigned)(((long long)(rr + (NT / 8) * p) * ld + c * EPC) * (long long)sizeof(T));
   } else {
     // stored (k x rows): BK k-rows of TS elements
     constexpr int CPR = TS / EPC;        // chunks per k-row
     constexpr int RPP = NT / CPR;        // k-rows per pass
     const int c = tid % CPR, kr = tid / CPR;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const T* g = base + (long long)(k0 + kr + RPP * p) * ld + row0 + c * EPC;
-      r[p] = *reinterpret_cast<const V16*>(g);
-    }
+    for (int p = 0; p < NP; ++p) voff[p] = (unsigned)(((long long)(kr + RPP * p) * ld + c * EPC) * (long long)sizeof(T));
   }
+}
+// buffer_load_dwordx4 with the k-tile's base in a scalar resource descriptor and the lane's 32-bit offset in one
+// VGPR (raw buffer, no stride, 2 GB window: the offsets stay below TS rows x ld, < 2^27 bytes)
+template <int NP>
+__device__ __forceinline__ void load_tile(const char* __restrict__ ubase, const unsigned (&voff)[NP], V16 (&r)[NP]) {
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) r[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], 0, 0);
 }
 
 template <typename T, bool TR, int NT, int TS>
@@ -369,29 +376,47 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     // (Measured and not kept - DESIGN.md: fetch pinned to the top or the middle of the MFMAs with
     // sched_barrier, s_setprio around the MFMAs: equal or slower on the throughput shapes; 2 or 4 k-tiles per
     // iteration for the 64-tile small-grid configuration: no gain.)
-    V16 ra[TS * 8 / NT], rb[TS * 8 / NT];
-    load_tile<T, TA, NT, TS>(A, p.lda, row0, kb, tid, ra);
-    load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb, tid, rb);
+    constexpr int NP = TS * 8 / NT;
+    V16 ra[NP], rb[NP];
+    unsigned offa[NP], offb[NP];
+    tile_offsets<T, TA, NT, TS>(p.lda, tid, offa);
+    tile_offsets<T, TB, NT, TS>(p.ldb, tid, offb);
+    // wave-uniform bases of k-tile 0 and the byte step between k-tiles (k contiguous: BK elements; k strided: BK rows)
+    const long long es = sizeof(T);
+    const char* ua = reinterpret_cast<const char*>(A) + (TA ? ((long long)kb * p.lda + row0) : ((long long)row0 * p.lda + kb)) * es;
+    const char* ub = reinterpret_cast<const char*>(B) + (TB ? ((long long)kb * p.ldb + col0) : ((long long)col0 * p.ldb + kb)) * es;
+    const long long sa = (TA ? (long long)BK * p.lda : (long long)BK) * es;
+    const long long sb = (TB ? (long long)BK * p.ldb : (long long)BK) * es;
+    load_tile<NP>(ua, offa, ra);
+    load_tile<NP>(ub, offb, rb);
     store_tile<T, TA, NT, TS>(lds, tid, ra);
     store_tile<T, TB, NT, TS>(lds + LDS_OP_BYTES, tid, rb);
     {
       const int k1 = min(1, nkt - 1);
-      load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + k1 * BK, tid, ra);
-      load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + k1 * BK, tid, rb);
+      load_tile<NP>(ua + k1 * sa, offa, ra);
+      load_tile<NP>(ub + k1 * sb, offb, rb);
     }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int cur = kt & 1;
+    // two k-tiles per trip so that the LDS buffer index is a compile-time constant (immediate offsets on every
+    // ds instruction, no vector address arithmetic in the body)
+    auto body = [&](int kt, auto curc) {
+      constexpr int cur = decltype(curc)::value;
       store_tile<T, TA, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
       store_tile<T, TB, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
       const int kn = min(kt + 2, nkt - 1);
       const char* la = lds + cur * 2 * LDS_OP_BYTES;
       const char* lb = la + LDS_OP_BYTES;
-      load_tile<T, TA, NT, TS>(A, p.lda, row0, kb + kn * BK, tid, ra);
-      load_tile<T, TB, NT, TS>(B, p.ldb, col0, kb + kn * BK, tid, rb);
+      load_tile<NP>(ua + kn * sa, offa, ra);
+      load_tile<NP>(ub + kn * sb, offb, rb);
       compute_tile<TA, TB, AB, NB, TS>(la, lb, row_w, col_w, lane, acc);
       __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+      body(kt, IntC<0>{});
+      body(kt + 1, IntC<1>{});
     }
+    if (kt < nkt) body(kt, IntC<0>{});
   }
   if constexpr (EPI == 0) {
     store_acc<AB, NB>(C, p.ldc, row0 + row_w, col0 + col_w, lane, acc, p.alpha, p.beta);
