@@ -26,6 +26,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_GEMM_WM_F64")) h->gemm_wm_f64 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
+  if (const char* e = getenv("GPK_K5_SUPER")) h->k5_super = atoi(e);
   if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
   *out = h;
   return GPK_OK;
@@ -132,6 +133,7 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   g.ke0 = GPK_TILE;
   g.ke_row = GPK_TILE;
   g.epilogue = 1;
+  g.k_super = h->k5_super;   // W is zero right of the diagonal for 8 tiles (gpk_trtri, gpk_tril_to_f32)
   g.heavy_first = 1;   // row tile tm costs (tm + 1) k-blocks: start the long ones first
   const int ntm = (int)(Np / gpk_gemm_tile(h, g));       // one partial row per tile row of the launch
   void* partial = nullptr;

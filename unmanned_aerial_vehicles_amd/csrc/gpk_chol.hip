@@ -214,10 +214,11 @@ __global__ void unpack_rhs_kernel(const double* __restrict__ Yp, long long N, in
 }
 __global__ void tril_to_f32_kernel(const double* __restrict__ L, long long Np, long long ldl,
                                    float* __restrict__ Lf, long long ldlf) {
-  // row = blockIdx.x; only the lower triangle and the rest of the diagonal tile are written
+  // row = blockIdx.x; the lower triangle is converted and the band of GPK_ZERO_BAND_TILES tiles from the diagonal
+  // tile rightwards is zeroed (the K5 launch reads that far: k_super in gpk_gemm)
   const long long i = blockIdx.x;
   const long long j = (long long)blockIdx.y * 256 + threadIdx.x;
-  const long long jend = (i / NB + 1) * NB;
+  const long long jend = min(Np, (i / NB + GPK_ZERO_BAND_TILES) * NB);
   if (j >= jend) return;
   Lf[i * ldlf + j] = (j <= i) ? (float)L[i * ldl + j] : 0.f;
 }
@@ -446,11 +447,27 @@ extern "C" int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t l
   return GPK_OK;
 }
 
+// zero the tiles right of each diagonal tile of W (GPK_ZERO_BAND_TILES - 1 of them): the K5 launch gives every
+// row of an 8-row super-tile the k-range of its longest row and relies on zeros beyond a row's own range
+__global__ void zero_band_kernel(double* __restrict__ W0, long long Np, long long ldw, long long strideW) {
+  double* __restrict__ W = reinterpret_cast<double*>(reinterpret_cast<char*>(W0) + blockIdx.z * strideW);
+  const long long i = blockIdx.x;
+  const long long j0 = (i / NB + 1) * NB, j1 = min(Np, (i / NB + GPK_ZERO_BAND_TILES) * NB);
+  const long long j = j0 + (long long)blockIdx.y * 256 + threadIdx.x;
+  if (j < j1) W[i * ldw + j] = 0.0;
+}
+
 extern "C" int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
                          int64_t ldw, double* work) {
   if (!h) return GPK_BAD_ARG;
   GPK_REQUIRE(h, L && winv && W && work, "trtri: null pointer");
   GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldl >= Np && ldw >= Np, "trtri: Np must be a multiple of 128");
+  if (Np > NB) {
+    const unsigned ny = (unsigned)(((GPK_ZERO_BAND_TILES - 1) * NB + 255) / 256);
+    hipLaunchKernelGGL(zero_band_kernel, dim3((unsigned)Np, ny, (unsigned)h->batch), dim3(256), 0, h->stream, W,
+                       (long long)Np, (long long)ldw, gpk_bstride(h, W));
+    GPK_LAUNCH_CHECK(h);
+  }
   const int64_t n1 = half_split(Np);
   return trtri_rec(h, L, ldl, Np, winv, W, ldw, work, n1 > 0 ? n1 : NB);
 }

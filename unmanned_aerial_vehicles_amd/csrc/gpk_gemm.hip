@@ -34,6 +34,7 @@ struct KParams {
   int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;   // k-range coefficients per 128-row tile index
   int ntm, ntn;
   int heavy_first;            // reverse the tile-row order (k-range grows with the row: longest tiles first)
+  int k_super;
   int direct, nst, nsc, sr;   // tile mapping: direct grid, or super-tiles (count, per super-row, rows)
 };
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   // workgroups: the 8 + 8 operand panels of a super-tile are shared through that XCD's L2, and every
   // XCD sees an even sample of the tile grid (triangular problems stay balanced).  lower_only
   // enumerates only the super-tiles on or below the diagonal.
-  int tm, tn;
+  int tm, tn, tmk = -1;
   if (p.direct) {
     tm = blockIdx.x % p.ntm;
     tn = blockIdx.x / p.ntm;
@@ -347,12 +348,14 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     tm = p.sr * R + (slot & (p.sr - 1));
     tn = (64 / p.sr) * S + slot / p.sr;
     if (tm >= p.ntm || tn >= p.ntn) return;
+    if (p.k_super) tmk = p.heavy_first ? p.ntm - 1 - p.sr * R : min(p.sr * R + p.sr - 1, p.ntm - 1);
   }
   if (p.heavy_first) tm = p.ntm - 1 - tm;
+  if (tmk < 0) tmk = tm;
   if (p.lower_only && tn > tm) return;
 
   // k-range of this tile; the coefficients are given per 128-row tile index
-  const int tm128 = tm * TS / 128, tn128 = tn * TS / 128;
+  const int tm128 = tmk * TS / 128, tn128 = tn * TS / 128;
   int kb = p.kb0 + p.kb_row * tm128 + p.kb_col * tn128;
   int ke = p.ke0 < 0 ? p.k : p.ke0 + p.ke_row * tm128 + p.ke_col * tn128;
   kb = max(kb, 0);
@@ -438,6 +441,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
   p.ke0 = g.ke0; p.ke_row = g.ke_row; p.ke_col = g.ke_col;
   p.heavy_first = g.heavy_first;
+  p.k_super = g.k_super;
   p.ntm = g.m / TS; p.ntn = g.n / TS;
   const long long ntiles = g.lower_only ? (long long)p.ntm * (p.ntm + 1) / 2 : (long long)p.ntm * p.ntn;
   p.direct = ntiles <= 512 ? 1 : 0;

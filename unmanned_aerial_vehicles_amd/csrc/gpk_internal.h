@@ -30,6 +30,7 @@ struct gpk_context {
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 128;
+  int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // batched mode (gpk_batch_begin .. gpk_batch_end): `batch` same-shaped problems per call.  Pointers passed
   // to the entry points address problem 0; a pointer that falls inside a registered buffer advances by that
@@ -89,6 +90,8 @@ inline long long gpk_bstride(gpk_handle h, const void* p) {
 // m, n multiples of 128; k multiple of 16.  lower_only skips tiles strictly above the
 // diagonal.  Per-tile k range: [kb0 + kb_row * tile_row + kb_col * tile_col,
 // ke0 + ke_row * tile_row + ke_col * tile_col) clipped to [0, k) (ke0 < 0 means "k").
+constexpr int GPK_ZERO_BAND_TILES = 8;   // tiles from the diagonal tile rightwards that gpk_trtri / gpk_tril_to_f32 zero
+
 struct GemmArgs {
   const void* A;
   const void* B;
@@ -100,6 +103,8 @@ struct GemmArgs {
   int lower_only;
   int kb0, kb_row, kb_col, ke0, ke_row, ke_col;
   int heavy_first;  // process tile rows in reverse order (use when the k-range grows with the tile row)
+  int k_super;      // every row of an 8-row super-tile takes the k-range of its longest row (the operand must be
+                    // zero beyond each row's own range): the 64 workgroups of a super-tile then run in lockstep
   int epilogue;   // 0: store C;  1: C (fp64, ld = ldc) [tile_row][col] = sum over the tile's rows of (alpha*acc)^2
 };
 inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb,
@@ -107,7 +112,7 @@ inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.m = m; g.n = n; g.k = k; g.ta = ta; g.tb = tb; g.alpha = alpha; g.beta = beta;
-  g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0; g.epilogue = 0; g.heavy_first = 0;
+  g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0; g.epilogue = 0; g.heavy_first = 0; g.k_super = 0;
   return g;
 }
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);
