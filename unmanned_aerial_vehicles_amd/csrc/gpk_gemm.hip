@@ -334,20 +334,42 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
     if (st >= p.nst) return;
     int R, S;
+    bool placed = false;
     if (p.lower_only) {
-      R = (int)((__builtin_sqrtf(8.0f * (float)st + 1.0f) - 1.0f) * 0.5f);
-      while ((R + 1) * (R + 2) / 2 <= st) ++R;
-      while (R * (R + 1) / 2 > st) --R;
-      S = st - R * (R + 1) / 2;
+      // Lower triangle: first the super-tiles strictly below the diagonal (all 64 tiles active), then the
+      // 36 active tiles of each diagonal super-tile packed 64 to a group - no workgroup exits early in the
+      // middle of the grid, so the 64 workgroups of an XCD stay in lockstep (early exits on the diagonal let
+      // the successors start half a tile apart; they never re-align and stop sharing operand panels in L2).
+      const int nsr = (p.ntm + 7) / 8, noff = nsr * (nsr - 1) / 2;
+      if (st < noff) {
+        R = (int)((1.0f + __builtin_sqrtf(8.0f * (float)st + 1.0f)) * 0.5f);
+        while (R * (R + 1) / 2 <= st) ++R;
+        while (R * (R - 1) / 2 > st) --R;
+        S = st - R * (R - 1) / 2;
+      } else {
+        const int t = (st - noff) * 64 + slot;
+        if (t >= 36 * nsr) return;
+        const int d = t / 36, u = t - 36 * d;
+        int i = (int)((__builtin_sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= u) ++i;
+        while (i * (i + 1) / 2 > u) --i;
+        tm = 8 * d + i;
+        tn = 8 * d + (u - i * (i + 1) / 2);
+        R = d; S = d;
+        placed = true;
+        if (tm >= p.ntm) return;
+      }
     } else {
       R = st / p.nsc;
       S = st - R * p.nsc;
       S = (S + R) % p.nsc;   // rotate per super-row: with nsc % 8 == 0 an XCD would otherwise always get the
                              // same super-columns (unbalanced when the k-range depends on the column)
     }
-    tm = p.sr * R + (slot & (p.sr - 1));
-    tn = (64 / p.sr) * S + slot / p.sr;
-    if (tm >= p.ntm || tn >= p.ntn) return;
+    if (!placed) {
+      tm = p.sr * R + (slot & (p.sr - 1));
+      tn = (64 / p.sr) * S + slot / p.sr;
+      if (tm >= p.ntm || tn >= p.ntn) return;
+    }
     if (p.k_super) tmk = p.heavy_first ? p.ntm - 1 - p.sr * R : min(p.sr * R + p.sr - 1, p.ntm - 1);
   }
   if (p.heavy_first) tm = p.ntm - 1 - tm;
@@ -453,7 +475,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   const int sc = 64 / p.sr;
   const int nsr = (p.ntm + p.sr - 1) / p.sr;
   p.nsc = (p.ntn + sc - 1) / sc;
-  p.nst = g.lower_only ? nsr * (nsr + 1) / 2 : nsr * p.nsc;
+  p.nst = g.lower_only ? nsr * (nsr - 1) / 2 + (36 * nsr + 63) / 64 : nsr * p.nsc;
   const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
   if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
   dim3 grid((unsigned)nblocks, (unsigned)h->batch), block(WM * 128);
