@@ -340,10 +340,13 @@ int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const doubl
   // T (n2 x n1) = L21 * W11   (W11 lower: k >= column tile start)
   GemmArgs g = gemm_args(L + n1 * ldl, ldl, 0, W, ldw, 1, T, ldt, (int)n2, (int)n1, (int)n1, 1.0, 0.0);
   g.kb_col = NB;
+  g.k_super = 1;           // W is zero right of the diagonal for 8 tiles (zero_band_kernel)
   GPK_TRY(gpk_gemm(h, GPK_F64, g));
   // W21 = -W22 * T          (W22 lower: k < row tile end)
   GemmArgs g2 = gemm_args(W + n1 * ldw + n1, ldw, 0, T, ldt, 1, W + n1 * ldw, ldw, (int)n2, (int)n1, (int)n2, -1.0, 0.0);
   g2.ke0 = NB; g2.ke_row = NB;
+  g2.k_super = 1;
+  g2.heavy_first = 1;      // row tile r costs r + 1 k-blocks: longest first
   return gpk_gemm(h, GPK_F64, g2);
 }
 
@@ -490,6 +493,7 @@ extern "C" int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, d
   GemmArgs g = gemm_args(W, ldw, 1, W, ldw, 1, Kinv, ldk, (int)Np, (int)Np, (int)Np, 1.0, 0.0);
   g.lower_only = 1;
   g.kb_row = NB;
+  g.k_super = 1;           // W (from gpk_trtri) is zero above the diagonal for 8 tiles
   return gpk_gemm(h, GPK_F64, g);
 }
 

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   // workgroups: the 8 + 8 operand panels of a super-tile are shared through that XCD's L2, and every
   // XCD sees an even sample of the tile grid (triangular problems stay balanced).  lower_only
   // enumerates only the super-tiles on or below the diagonal.
-  int tm, tn, tmk = -1;
+  int tm, tn;
+  int rlo = -1, rhi = -1, clo = -1, chi = -1;   // k_super: extreme tile rows / columns of the super-tile
   if (p.direct) {
     tm = blockIdx.x % p.ntm;
     tn = blockIdx.x / p.ntm;
@@ -370,16 +371,24 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
       tn = (64 / p.sr) * S + slot / p.sr;
       if (tm >= p.ntm || tn >= p.ntn) return;
     }
-    if (p.k_super) tmk = p.heavy_first ? p.ntm - 1 - p.sr * R : min(p.sr * R + p.sr - 1, p.ntm - 1);
+    if (p.k_super) {
+      // the super-tile's tile rows [r0, r1] and columns [c0, c1] (placed: a packed group of diagonal tiles)
+      const int r0 = p.lower_only ? 8 * R : p.sr * R, r1 = min(r0 + (p.lower_only ? 8 : p.sr) - 1, p.ntm - 1);
+      const int c0 = p.lower_only ? 8 * S : (64 / p.sr) * S, c1 = min(c0 + (p.lower_only ? 8 : 64 / p.sr) - 1, p.ntn - 1);
+      rlo = p.heavy_first ? p.ntm - 1 - r1 : r0;
+      rhi = p.heavy_first ? p.ntm - 1 - r0 : r1;
+      clo = c0; chi = c1;
+    }
   }
   if (p.heavy_first) tm = p.ntm - 1 - tm;
-  if (tmk < 0) tmk = tm;
+  if (rlo < 0) { rlo = rhi = tm; clo = chi = tn; }
   if (p.lower_only && tn > tm) return;
 
   // k-range of this tile; the coefficients are given per 128-row tile index
-  const int tm128 = tmk * TS / 128, tn128 = tn * TS / 128;
-  int kb = p.kb0 + p.kb_row * tm128 + p.kb_col * tn128;
-  int ke = p.ke0 < 0 ? p.k : p.ke0 + p.ke_row * tm128 + p.ke_col * tn128;
+  // (k_super: the union of the k-ranges of the super-tile's tiles - the coefficients are >= 0, so the lowest
+  // row / column gives the start and the highest the end; the operands are zero outside a tile's own range)
+  int kb = p.kb0 + p.kb_row * (rlo * TS / 128) + p.kb_col * (clo * TS / 128);
+  int ke = p.ke0 < 0 ? p.k : p.ke0 + p.ke_row * (rhi * TS / 128) + p.ke_col * (chi * TS / 128);
   kb = max(kb, 0);
   ke = min(ke, p.k);
   const int nkt = (ke - kb) / BK;
