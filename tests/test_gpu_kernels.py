@@ -258,6 +258,40 @@ def test_predict_mean_mfma(be, N, D, P, M, ls):
     assert dev.mean_kernel_choice() == "valu"
 
 
+@pytest.mark.parametrize("Np", [4096, 4224])
+def test_trtri_wtw_super_tile_sizes(be, Np):
+    """W = L^-1 and K^-1 = W^T W at sizes where the GEMMs run in super-tile mode (> 512 tiles: lockstep k-ranges
+    over the zero band right of W's diagonal, packed diagonal groups; 33 tile rows = odd count) against torch's
+    fp64 triangular solve / matmul on the same device."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(Np)
+    A = torch.randn((Np, Np), dtype=torch.float64, generator=g)
+    L = torch.tril(A) * 0.02
+    L.diagonal().copy_(1.0 + torch.rand(Np, dtype=torch.float64, generator=g))
+    Ld = L.to(be.device).contiguous()
+    # garbage above the diagonal must be ignored by the factor consumers
+    Ld += torch.triu(torch.full((Np, Np), 7.0, dtype=torch.float64, device=be.device), diagonal=1)
+    winv = be.empty((Np, 128), torch.float64)
+    W = torch.full((Np, Np), float("nan"), dtype=torch.float64, device=be.device)     # trtri must not rely on a cleared W
+    work = be.empty(((Np // 2 + 128) ** 2,), torch.float64)
+    be.bind_stream()
+    be.check(be.lib.gpk_leaf_inverses(be.h, _p(Ld), Np, Np, _p(winv)))
+    be.check(be.lib.gpk_trtri(be.h, _p(Ld), Np, Np, _p(winv), _p(W), Np, _p(work)))
+    Wl = torch.tril(W)
+    Ll = torch.tril(Ld)
+    eye = torch.eye(Np, dtype=torch.float64, device=be.device)
+    assert float(torch.max(torch.abs(Wl @ Ll - eye))) < 1e-11
+    band = torch.triu(W, diagonal=1)
+    tile = torch.arange(Np, device=be.device) // 128
+    in_band = (tile[None, :] - tile[:, None] <= 7) & (torch.arange(Np, device=be.device)[None, :] > torch.arange(Np, device=be.device)[:, None])
+    assert bool(torch.all(band[in_band] == 0.0))                  # the zero band the lockstep launches rely on
+    Kinv = torch.zeros((Np, Np), dtype=torch.float64, device=be.device)
+    be.check(be.lib.gpk_wtw(be.h, _p(W), Np, Np, _p(Kinv), Np))
+    ref = Wl.T @ Wl
+    lower = torch.tril(torch.ones((Np, Np), dtype=torch.bool, device=be.device))
+    assert float(torch.max(torch.abs(Kinv[lower] - ref[lower]))) < 1e-11 * float(torch.max(torch.abs(ref)))
+
+
 def test_lml_gradient_kernels(be, csv_data, ka):
     from unmanned_aerial_vehicles_amd.device import DeviceGP
     X, Y = csv_data["X10"][:, :9], csv_data["Y6"][:, 3:6]
