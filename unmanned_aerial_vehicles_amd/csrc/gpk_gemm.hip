@@ -315,12 +315,10 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   const int row_w = wm * (TS / WM), col_w = wn * (TS / 2);
 
   // ---- tile mapping.  Grids that fit one residency round (<= 512 tiles) map block -> tile directly.
-  // Larger grids are cut into super-tiles of 64 tiles (8 x 8, or sr x 64/sr for short grids); hardware
-  // workgroup b runs on XCD b % 8 (round-robin dispatch, verified with HW_REG_XCC_ID), so XCD x takes
-  // super-tiles x, x+8, x+16, ... and walks the 64 tiles of one super-tile with its 64 resident
-  // workgroups: the 8 + 8 operand panels of a super-tile are shared through that XCD's L2, and every
-  // XCD sees an even sample of the tile grid (triangular problems stay balanced).  lower_only
-  // enumerates only the super-tiles on or below the diagonal.
+  // Larger grids are cut into super-tiles of 64 tiles; hardware workgroup b runs on XCD b % 8 (round-robin
+  // dispatch, verified with HW_REG_XCC_ID), so an XCD walks the 64 tiles of one super-tile with its 64 resident
+  // workgroups: the 8 + 8 operand panels of a super-tile are shared through that XCD's L2, and every XCD sees
+  // an even sample of the tile grid (triangular problems stay balanced).
   int tm, tn;
   int rlo = -1, rhi = -1, clo = -1, chi = -1;   // k_super: extreme tile rows / columns of the super-tile
   if (p.direct) {
@@ -334,19 +332,21 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     const int grp = j >> 6, slot = j & 63;
     const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
     if (st >= p.nst) return;
-    int R, S;
-    bool placed = false;
     if (p.lower_only) {
       // Lower triangle: first the super-tiles strictly below the diagonal (all 64 tiles active), then the
       // 36 active tiles of each diagonal super-tile packed 64 to a group - no workgroup exits early in the
       // middle of the grid, so the 64 workgroups of an XCD stay in lockstep (early exits on the diagonal let
       // the successors start half a tile apart; they never re-align and stop sharing operand panels in L2).
       const int nsr = (p.ntm + 7) / 8, noff = nsr * (nsr - 1) / 2;
+      int R, S;
       if (st < noff) {
         R = (int)((1.0f + __builtin_sqrtf(8.0f * (float)st + 1.0f)) * 0.5f);
         while (R * (R + 1) / 2 <= st) ++R;
         while (R * (R - 1) / 2 > st) --R;
         S = st - R * (R - 1) / 2;
+        tm = 8 * R + (slot & 7);
+        tn = 8 * S + (slot >> 3);
+        if (tm >= p.ntm) return;
       } else {
         const int t = (st - noff) * 64 + slot;
         if (t >= 36 * nsr) return;
@@ -357,28 +357,38 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
         tm = 8 * d + i;
         tn = 8 * d + (u - i * (i + 1) / 2);
         R = d; S = d;
-        placed = true;
         if (tm >= p.ntm) return;
       }
+      if (p.k_super) {
+        rlo = 8 * R; rhi = min(8 * R + 7, p.ntm - 1);
+        clo = 8 * S; chi = min(8 * S + 7, p.ntn - 1);
+      }
     } else {
-      R = st / p.nsc;
-      S = st - R * p.nsc;
-      S = (S + R) % p.nsc;   // rotate per super-row: with nsc % 8 == 0 an XCD would otherwise always get the
-                             // same super-columns (unbalanced when the k-range depends on the column)
+      // Full rectangle: bands of sr tile rows (8; adapted for short or narrow grids), walked column by column,
+      // cut into groups of 64 consecutive tiles = one super-tile (8 x 8 when the width is a multiple of 8;
+      // otherwise a group runs on into the next band instead of leaving slots idle: 79 tile columns, the K5
+      // batch of 10 000 queries, would leave every tenth super-tile 1/8 empty).
+      const int sr = p.sr, per = sr * p.ntn, nfull = p.ntm / sr, hlast = p.ntm - nfull * sr;
+      const int total = p.ntm * p.ntn;
+      auto place = [&](int t, int& row, int& col, int& band) {
+        band = min(t / per, nfull);
+        const int idx = t - band * per, hh = band < nfull ? sr : hlast;
+        col = idx / hh;
+        row = band * sr + (idx - col * hh);
+      };
+      const int t = st * 64 + slot;
+      if (t >= total) return;
+      int band;
+      place(t, tm, tn, band);
+      if (p.k_super) {
+        int r0, c0, b0, r1, c1, b1;
+        place(st * 64, r0, c0, b0);
+        place(min(st * 64 + 63, total - 1), r1, c1, b1);
+        rlo = b0 * sr; rhi = min(b1 * sr + sr - 1, p.ntm - 1);
+        if (b0 == b1) { clo = c0; chi = c1; } else { clo = 0; chi = p.ntn - 1; }
+      }
     }
-    if (!placed) {
-      tm = p.sr * R + (slot & (p.sr - 1));
-      tn = (64 / p.sr) * S + slot / p.sr;
-      if (tm >= p.ntm || tn >= p.ntn) return;
-    }
-    if (p.k_super) {
-      // the super-tile's tile rows [r0, r1] and columns [c0, c1] (placed: a packed group of diagonal tiles)
-      const int r0 = p.lower_only ? 8 * R : p.sr * R, r1 = min(r0 + (p.lower_only ? 8 : p.sr) - 1, p.ntm - 1);
-      const int c0 = p.lower_only ? 8 * S : (64 / p.sr) * S, c1 = min(c0 + (p.lower_only ? 8 : 64 / p.sr) - 1, p.ntn - 1);
-      rlo = p.heavy_first ? p.ntm - 1 - r1 : r0;
-      rhi = p.heavy_first ? p.ntm - 1 - r0 : r1;
-      clo = c0; chi = c1;
-    }
+    if (p.k_super && p.heavy_first) { const int a0 = p.ntm - 1 - rhi, a1 = p.ntm - 1 - rlo; rlo = a0; rhi = a1; }
   }
   if (p.heavy_first) tm = p.ntm - 1 - tm;
   if (rlo < 0) { rlo = rhi = tm; clo = chi = tn; }
@@ -472,7 +482,6 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
   p.ke0 = g.ke0; p.ke_row = g.ke_row; p.ke_col = g.ke_col;
   p.heavy_first = g.heavy_first;
-  p.k_super = g.k_super;
   p.ntm = g.m / TS; p.ntn = g.n / TS;
   const long long ntiles = g.lower_only ? (long long)p.ntm * (p.ntm + 1) / 2 : (long long)p.ntm * p.ntn;
   p.direct = ntiles <= 512 ? 1 : 0;
@@ -484,7 +493,10 @@ int launch(gpk_handle h, const GemmArgs& g) {
   const int sc = 64 / p.sr;
   const int nsr = (p.ntm + p.sr - 1) / p.sr;
   p.nsc = (p.ntn + sc - 1) / sc;
-  p.nst = g.lower_only ? nsr * (nsr - 1) / 2 + (36 * nsr + 63) / 64 : nsr * p.nsc;
+  p.nst = g.lower_only ? nsr * (nsr - 1) / 2 + (36 * nsr + 63) / 64 : (int)(((long long)p.ntm * p.ntn + 63) / 64);
+  // k_super widens a tile's k-range to that of its super-tile, which spans at most two bands of sr tile rows:
+  // allowed only while that stays inside the zero band the producers of triangular operands guarantee
+  p.k_super = (g.k_super && 2 * p.sr * (TS / 64) <= 2 * GPK_ZERO_BAND_TILES) ? 1 : 0;
   const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
   if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
   dim3 grid((unsigned)nblocks, (unsigned)h->batch), block(WM * 128);

@@ -90,7 +90,9 @@ inline long long gpk_bstride(gpk_handle h, const void* p) {
 // m, n multiples of 128; k multiple of 16.  lower_only skips tiles strictly above the
 // diagonal.  Per-tile k range: [kb0 + kb_row * tile_row + kb_col * tile_col,
 // ke0 + ke_row * tile_row + ke_col * tile_col) clipped to [0, k) (ke0 < 0 means "k").
-constexpr int GPK_ZERO_BAND_TILES = 8;   // tiles from the diagonal tile rightwards that gpk_trtri / gpk_tril_to_f32 zero
+// tiles from the diagonal tile rightwards that gpk_trtri / gpk_tril_to_f32 zero; a k_super launch may read that far
+// beyond a row's own k-range (a super-tile spans at most two bands of 8 tile rows)
+constexpr int GPK_ZERO_BAND_TILES = 16;
 
 struct GemmArgs {
   const void* A;
