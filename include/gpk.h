@@ -181,14 +181,14 @@ int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, co
 /* ---- K5, serving form: variance through the explicit inverse factor ---------------------------------
  * gpk_trtri: W (dev Np x ldw, fp64) <- L^-1, lower triangle by tiles (recursive, fp64-MFMA GEMMs);
  * one-off N^3/3 flops after the factorisation.  work: dev double[(Np/2 + 128)^2].  Besides the lower
- * triangle it writes zeros into the 7 tiles to the right of every diagonal tile (see below).
+ * triangle it writes zeros into the 15 tiles to the right of every diagonal tile (see below).
  * gpk_tril_to_f32: fp32 copy of the lower triangle, with the same band of zeros right of the diagonal.
  * gpk_predict_var_inv: var[m] = max(kss - |W k*_m|^2, floor) in ONE GEMM launch: the tile of
  * V = W K*^T is reduced to column sums of squares in the epilogue and never written to HBM; W's
- * zero upper triangle is skipped (N^2 M flops, + 1.4 %: the 8 tile rows of a super-tile all run to the
+ * zero upper triangle is skipped (N^2 M flops, + 1.4 %: the tile rows of a super-tile all run to the
  * end of the longest row so that its 64 workgroups stay in lockstep and share operand panels through L2 -
- * W must therefore be ZERO above the diagonal for 8 tiles (1024 columns) to the right of each row's
- * diagonal tile, which gpk_trtri and gpk_tril_to_f32 guarantee).  W, X, Xq of `dtype`; work: dev scratch
+ * W must therefore be ZERO above the diagonal for 16 tiles (2048 columns) from each row's diagonal tile
+ * rightwards, which gpk_trtri and gpk_tril_to_f32 guarantee).  W, X, Xq of `dtype`; work: dev scratch
  * of Mp * Np elements of `dtype`; var: dev double[Mp].
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485),
  * with solve_triangular(L, K*^T) evaluated as (L^-1) K*^T.                                          */
