@@ -92,6 +92,28 @@ def test_gemm_tiles_random_and_lower(be):
     assert np.array_equal(out[~tiles_lower], C0[~tiles_lower])
 
 
+@pytest.mark.parametrize("mt,nt", [(9, 78), (65, 8), (1, 650), (650, 1), (33, 33), (16, 79), (7, 100), (100, 7),
+                                   (3, 200), (130, 5), (24, 24), (5, 103)])
+def test_gemm_tile_mapping_shapes(be, mt, nt):
+    """Every output tile is computed exactly once whatever the shape of the tile grid: direct grids (<= 512
+    tiles), 8-row bands whose width is not a multiple of 8 (groups running on into the next band), short and
+    narrow grids (adapted band height), one-row / one-column grids; both operand dtypes' tile paths share the
+    mapping, so fp64 with a short k is enough."""
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    m, n, k = 128 * mt, 128 * nt, 64
+    g = torch.Generator(device="cpu").manual_seed(mt * 1000 + nt)
+    A = torch.randint(-3, 4, (m, k), generator=g).double().to(be.device)
+    B = torch.randint(-3, 4, (n, k), generator=g).double().to(be.device)
+    Cm = torch.full((m, n), float("nan"), dtype=torch.float64, device=be.device)
+    be.bind_stream()
+    be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(A), k, _p(B), k, _p(Cm), n, m, n, k, 1.0, 0.0, 0))
+    assert torch.equal(Cm, A @ B.T)                       # integer data: exact
+    # accumulate on top: a tile visited twice (or never) would show
+    be.check(be.lib.gpk_gemm_tiles(be.h, _lib.GPK_F64, 0, 0, _p(A), k, _p(B), k, _p(Cm), n, m, n, k, 1.0, 1.0, 0))
+    assert torch.equal(Cm, 2.0 * (A @ B.T))
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,D,ard", [(1000, 9, False), (1000, 10, True), (130, 3, False), (64, 20, True)])
 def test_gram_fp64(be, csv_data, N, D, ard):
