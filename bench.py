@@ -36,7 +36,7 @@ MFMA_F64_PEAK_TF = 78.6       # fp64 matrix peak (MI355X datasheet; used for the
 # HBM/fabric bytes per launch of the dominant kernel at the default configuration, from the PMC passes
 # committed in profiles/r01_bench_pmc_hbm_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the factor 2
 # being the gfx950 FETCH_SIZE correction for 16-byte-per-lane streams (MI355X_MICROARCH.md, HBM section).
-PMC_TRAFFIC_BYTES = {("inverse", 65536, 10000): 4.749e11}
+PMC_TRAFFIC_BYTES = {("inverse", 65536, 10000): 2.937e11}
 
 
 def synthetic_problem(N, M, D=9, P=3, qseed=1):
@@ -116,7 +116,21 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout must carry exactly
+        # one JSON line, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(8, device=torch.device("cuda", local_rank))
+            dist.all_reduce(warm)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend, padded

@@ -33,3 +33,5 @@ PY
 rm -rf $out/prof $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 python bench.py --workload c4 --steps 5 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 rc=$?"
 python -u tools/run_configs.py > $out/run_configs.log 2>&1; echo "run_configs rc=$?"; tail -3 $out/run_configs.log
+# the distributed code path (process group, RCCL all-gather) with the one rank this box has
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "torchrun rc=$?"
