@@ -158,6 +158,21 @@ int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int6
                           const double* ls, double sf2, const double* center, const double* y_mean,
                           const double* y_std, const float* Xq, int64_t M, float* mean);
 
+/* K5 on the bf16 matrix pipe at fp32 accuracy (exact operand split).
+ * gpk_split3: src (dev rows x ld fp32, cols % 16 == 0) -> dst (dev, rows * cols * 6 bytes): every fp32 value
+ * as three bf16 parts x = x0 + x1 + x2 (8 significant bits each, by truncation: the sum is exact), stored per
+ * row as 16-byte chunks [k16 block][half][part] (96 bytes per 16 columns).
+ * gpk_predict_var_inv_split: the same result as gpk_predict_var_inv(GPK_F32, ...) with W3 = gpk_split3 of the
+ * fp32 inverse factor (gpk_tril_to_f32 output, Np x Np): one launch whose 32 x 32 x 16 block products are six
+ * v_mfma_f32_32x32x16_bf16 each (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0; exact bf16 products, fp32
+ * accumulation; the dropped terms are below 2^-24 of |a||b|).  work: dev float[Mp * Np] (K* in fp32),
+ * work3: dev, Mp * Np * 6 bytes (its split); var: dev double[Mp].  X, Xq fp32.
+ * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485).       */
+int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst);
+int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+                              const void* W3, int64_t Np, const float* Xq, int64_t M, double kss, double floor_,
+                              float* work, void* work3, double* var);
+
 /* K4 for B (<= 8) independent single-output ARD models that share X (the per-axis GPs of
  * src/px4/gp_trainer.py:139-179, predicted one by one at src/px4/pretrained_gp.py:64-91): one launch
  * evaluates every model; the feature differences of a (query, training point) pair are formed once.

@@ -314,6 +314,54 @@ def test_trtri_wtw_super_tile_sizes(be, Np):
     assert float(torch.max(torch.abs(Kinv[lower] - ref[lower]))) < 1e-11 * float(torch.max(torch.abs(ref)))
 
 
+def test_split3_is_exact(be):
+    """gpk_split3: every fp32 value becomes three bf16 parts whose sum is the value exactly, laid out as
+    [k16 block][half][part] 16-byte chunks."""
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib  # noqa: F401
+    rows, cols = 37, 64
+    g = torch.Generator(device="cpu").manual_seed(11)
+    src = torch.randn((rows, cols), generator=g) * torch.exp(8.0 * torch.randn((rows, cols), generator=g))
+    src[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 65504.0, 1.0 + 2.0 ** -23, -(2.0 ** -100)])   # normal range
+    sd = src.to(be.device).contiguous()
+    dst = torch.zeros((rows * cols * 6,), dtype=torch.uint8, device=be.device)
+    be.bind_stream()
+    be.check(be.lib.gpk_split3(be.h, _p(sd), rows, cols, cols, _p(dst)))
+    raw = dst.cpu().numpy().view(np.uint16).reshape(rows, cols // 16, 2, 3, 8)      # [row][kb][h][part][j]
+    parts = (raw.astype(np.uint32) << 16).view(np.float32)                          # bf16 -> fp32 (exact)
+    total = parts[..., 0, :].astype(np.float64) + parts[..., 1, :].astype(np.float64) + parts[..., 2, :].astype(np.float64)
+    back = total.reshape(rows, cols // 16, 16).reshape(rows, cols)                  # k = 16 kb + 8 h + j
+    bad = np.argwhere(back != src.numpy().astype(np.float64))
+    assert bad.size == 0, (bad[:5], back[tuple(bad[0])], src.numpy()[tuple(bad[0])])
+    # the second and third parts are small: |x1| <= 2^-8 |x0|, |x2| <= 2^-16 |x0| (round-to-nearest split)
+    x0, x1, x2 = np.abs(parts[..., 0, :]), np.abs(parts[..., 1, :]), np.abs(parts[..., 2, :])
+    assert np.all(x1 <= x0 * 2.0 ** -8 + 1e-45) and np.all(x2 <= x0 * 2.0 ** -16 + 1e-45)
+
+
+@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130)])
+def test_variance_bf16_split_path(be, N, M):
+    """K5 with the exact bf16x3 operand split (six bf16 MFMAs per fp32 block product) against the fp64 path and
+    the fp32-MFMA path on the same queries: the same fp32 accuracy class (std within 1e-3 of fp64 - the stated
+    fp32 tolerance - and within 2x of the fp32-MFMA path's own error), in super-tile mode (N = 5000: 40 x 2 tiles
+    is direct; N = 3000 x 700: 24 x 6) and with ragged sizes."""
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(N)
+    X = rng.standard_normal((N, 9))
+    Y = np.sin(X @ rng.standard_normal((9, 2))) + 0.1 * rng.standard_normal((N, 2))
+    st_y = (Y - Y.mean(0)) / Y.std(0)
+    dev = DeviceGP(X, st_y, be)
+    dev.factorize(1.7, 1.0, 0.0501)
+    Xq = rng.standard_normal((M, 9))
+    v64 = dev.predict_var_dev(Xq, 1.05, 0.0, "float64", "inverse").cpu().numpy()
+    v32 = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse").cpu().numpy()
+    vsp = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split").cpu().numpy()
+    e32 = np.max(np.abs(np.sqrt(v32) - np.sqrt(v64)) / np.sqrt(v64))
+    esp = np.max(np.abs(np.sqrt(vsp) - np.sqrt(v64)) / np.sqrt(v64))
+    assert esp < 1e-3 and esp < 2.0 * e32 + 1e-6, (e32, esp)
+    with pytest.raises(ValueError):
+        dev.predict_var_dev(Xq, 1.05, 0.0, "float64", "inverse_split")
+
+
 def test_lml_gradient_kernels(be, csv_data, ka):
     from unmanned_aerial_vehicles_amd.device import DeviceGP
     X, Y = csv_data["X10"][:, :9], csv_data["Y6"][:, 3:6]

@@ -1,0 +1,300 @@
+// K5 on the bf16 matrix pipe at fp32 accuracy: V = W Kq^T with both fp32 operands split EXACTLY into three bf16
+// parts (x = x0 + x1 + x2, 8 significant bits each, by truncation; gpk_split3) and every 32 x 32 x 16 block
+// product formed by six v_mfma_f32_32x32x16_bf16 (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0: bf16 x bf16 products
+// are exact, accumulation is fp32, the dropped cross terms are below 2^-24 of |a||b|, i.e. below the rounding of
+// an fp32 FMA).  The fp32 MFMA runs at the vector rate (157 TF); the bf16 pipe is 16x faster, so six instructions
+// per fp32-equivalent product raise the ceiling of this launch by 16/6 = 2.7x.
+//
+// Operand layout (gpk_split3): row-major rows of 16-byte chunks [k16 block][half h][part s] - the eight bf16 of
+// part s for k = 16 kb + 8 h .. + 7 - so that one k-tile of 16 is 96 contiguous bytes per row (consecutive lanes
+// fetch consecutive chunks: a 144-byte-row LDS image fed by 32-byte pieces per row was 35 % slower) and a lane's
+// MFMA fragment (row r = lane & 31, k half h = lane >> 5) is one ds_read_b128 per part.  LDS rows are padded to
+// 112 bytes (28 dwords = 4 x odd: conflict-free b128 reads over 8 consecutive rows).
+//
+// The kernel is the K5 launch only: 128 x 128 tiles, 4 waves of 64 x 64 (2 x 2 blocks of 32 x 32), k-tiles of 16,
+// the same register-staged pipeline, scalar-based buffer loads, band-linear super-tiles in serpentine XCD order,
+// heavy-first rows and lockstep k-ranges as gemm_kernel (gpk_gemm.hip), and its epilogue reduces the tile to
+// per-column sums of squares (fp64) instead of storing it.
+//
+// Replaces the same reference lines as gpk_predict_var_inv (sklearn/gaussian_process/_gpr.py:454-485).
+#include "gpk_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int V16 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int V> struct IntC { static constexpr int value = V; };
+
+constexpr int ROWB = 96;       // bytes of one k-tile (16 k) of one row: 2 halves x 3 parts x 16 B
+constexpr int LROW = 112;      // padded LDS row
+constexpr int OPB = 128 * LROW;   // one operand k-tile in LDS
+
+// bf16 part of a finite fp32 value, rounded to nearest even (as bits in the upper half of a dword)
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+// x = x0 + x1 + x2 exactly, each part a bf16 obtained by rounding to nearest: |x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|
+// and the remainders are exact in fp32; the signs of x1, x2 are not tied to the sign of x, so the cross terms the
+// six-product scheme drops (x1 y2, x2 y1, x2 y2 <= 2^-26 |x y|) average out like rounding errors.  (Splitting by
+// truncation makes every part share the sign of x: the dropped terms then have the sign of x y and add up
+// coherently - measured 17x the error of the fp32 MFMA on the variance launch, whose row sums cancel heavily.)
+__device__ __forceinline__ void split3(float x, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = bf16_rn_bits(x);
+  const float r1 = x - __uint_as_float(h0);
+  h1 = bf16_rn_bits(r1);
+  const float r2 = r1 - __uint_as_float(h1);
+  h2 = __float_as_uint(r2);          // at most 8 significant bits left: the low half is zero
+}
+
+// src: rows x cols fp32 (ld elements per row, cols % 16 == 0) -> dst: rows x (cols / 16) x 96 bytes
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long long rows, long long cols,
+                                                     long long ld, V16* __restrict__ dst) {
+  const long long hc = cols / 8;                              // half-blocks of 8 k per row
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * hc) return;
+  const long long row = e / hc, hb = e - row * hc;            // hb = 2 kb + h
+  const float4* s4 = reinterpret_cast<const float4*>(src + row * ld + hb * 8);
+  const float4 lo = s4[0], hi = s4[1];
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  V16 f[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    split3(v[2 * j], a0, a1, a2);
+    split3(v[2 * j + 1], b0, b1, b2);
+    f[0][j] = (a0 >> 16) | b0;
+    f[1][j] = (a1 >> 16) | b1;
+    f[2][j] = (a2 >> 16) | (b2 & 0xffff0000u);
+  }
+  V16* d = dst + (row * hc + hb) * 3;
+  d[0] = f[0]; d[1] = f[1]; d[2] = f[2];
+}
+
+struct SParams {
+  const char* A;        // W, split layout, Np rows
+  const char* B;        // Kq, split layout, Mp rows
+  double* out;          // [ntm][Mp] partial column sums of squares
+  long long rsa, rsb;   // row strides in bytes (Np * 6)
+  long long Mp;
+  int ntm, ntn, nst;
+  float alpha;
+};
+
+template <int NP>
+__device__ __forceinline__ void load3(const char* __restrict__ ubase, const unsigned (&voff)[NP], V16 (&r)[NP]) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) r[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], 0, 0);
+}
+
+// WM wave rows x 2 wave columns per workgroup: WM = 2 -> 4 waves of 64 x 64, WM = 4 -> 8 waves of 32 x 64
+template <int WM>
+__global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * OPB];       // 2 stages x [A | B]
+  constexpr int NT = WM * 128, AB = 4 / WM, NQ = 1536 / NT;        // threads, 32-row blocks per wave, chunks per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row_w = wm * (128 / WM), col_w = wn * 64;
+
+  // ---- tile mapping: bands of 8 tile rows walked column by column in groups of 64 tiles, serpentine over XCDs
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int grp = j >> 6, slot = j & 63;
+  const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
+  if (st >= p.nst) return;
+  const int per = 8 * p.ntn, nfull = p.ntm / 8, hlast = p.ntm - nfull * 8, total = p.ntm * p.ntn;
+  auto place = [&](int t, int& row, int& col, int& band) {
+    band = min(t / per, nfull);
+    const int idx = t - band * per, hh = band < nfull ? 8 : hlast;
+    col = idx / hh;
+    row = band * 8 + (idx - col * hh);
+  };
+  const int t = st * 64 + slot;
+  if (t >= total) return;
+  int tm, tn, band;
+  place(t, tm, tn, band);
+  // heavy first: row r of the enumeration is tile row ntm-1-r (its k-range is (row + 1) * 128: longest first);
+  // every tile of the group runs to the end of the group's longest row, the one enumerated first (W is zero
+  // beyond a row's own range for 16 tiles; a group spans at most two bands = 16 tile rows)
+  const int band0 = min(st * 64 / per, nfull);
+  tm = p.ntm - 1 - tm;
+  const int rhi = p.ntm - 1 - band0 * 8;
+  const int nkt = (rhi + 1) * 8;                 // k-tiles of 16
+
+  const int row0 = tm * 128, col0 = tn * 128;
+  f16v acc[AB][2];
+#pragma unroll
+  for (int a = 0; a < AB; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // a k-tile is 768 chunks of 16 B per operand; chunk g = tid + NT q of the 1536 (A first, then B) is this thread's
+  // q-th; which operand it belongs to is wave-uniform
+  unsigned goff[NQ], lofs[NQ];
+  bool isb[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int g = tid + NT * q;
+    isb[q] = __builtin_amdgcn_readfirstlane(g >= 768 ? 1 : 0) != 0;
+    const int c = isb[q] ? g - 768 : g, row = c / 6, w = c - row * 6;
+    goff[q] = (unsigned)((long long)row * p.rsa + w * 16);
+    lofs[q] = (isb[q] ? OPB : 0) + row * LROW + w * 16;
+  }
+  const char* ua = p.A + (long long)row0 * p.rsa;
+  const char* ub = p.B + (long long)col0 * p.rsb;
+  // Register ring of RING k-tiles in flight: the fetch of k-tile kt+1+RING is issued when k-tile kt+1 leaves its
+  // ring slot for LDS.  The loop is unrolled by 4: slot and LDS buffer indices are constants.
+#ifndef GPK_K5S_SCHED
+#define GPK_K5S_SCHED 1
+#endif
+#ifndef GPK_K5S_RING
+#define GPK_K5S_RING 2
+#endif
+  constexpr int RING = GPK_K5S_RING;
+  V16 rr[RING][NQ];
+  auto fetch = [&](int tile, auto slotc) {
+    constexpr int sl = decltype(slotc)::value;
+    const long long ko = (long long)min(tile, nkt - 1) * ROWB;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((isb[q] ? ub : ua) + ko), 0, 0x7fffffff, 0x00020000);
+      rr[sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[q], 0, 0);
+    }
+  };
+  auto stage = [&](char* buf, auto slotc) {
+    constexpr int sl = decltype(slotc)::value;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) *reinterpret_cast<V16*>(buf + lofs[q]) = rr[sl][q];
+  };
+  fetch(0, IntC<0>{});
+  stage(lds, IntC<0>{});
+  fetch(1, IntC<1 % RING>{});
+  if constexpr (RING >= 2) fetch(2, IntC<2 % RING>{});
+  if constexpr (RING >= 3) fetch(3, IntC<3 % RING>{});
+  if constexpr (RING >= 4) { fetch(4, IntC<0>{}); }
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  // iteration kt (kt % RING == KS): k-tile kt+1 goes from ring slot (KS+1) % RING to LDS buffer (kt+1) & 1, that
+  // slot is refilled with k-tile kt+1+RING, and k-tile kt is multiplied out of LDS buffer kt & 1
+  auto body = [&](int kt, auto ksc) {
+    constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
+    stage(lds + (cur ^ 1) * 2 * OPB, IntC<sl>{});
+    fetch(kt + 1 + RING, IntC<sl>{});
+    const char* la = lds + cur * 2 * OPB;
+    const char* lb = la + OPB;
+    bf16x8 af[AB][3], bf[2][3];
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(la + (row_w + 32 * a + fr) * LROW + (fh * 3 + s) * 16));
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lb + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
+    // smallest terms first
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f16v c = acc[a][b];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+        acc[a][b] = c;
+      }
+#if GPK_K5S_SCHED
+    // issue order: LDS writes of the next k-tile, all twelve fragment reads, then the MFMAs with the six
+    // buffer loads spread among them (the scheduler otherwise trickles the reads between MFMAs and waits five times)
+    __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * AB + 6, 0);
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 12 * AB / NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#endif
+    __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 3 < nkt; kt += 4) {
+    body(kt, IntC<0 % RING>{});
+    body(kt + 1, IntC<1 % RING>{});
+    body(kt + 2, IntC<2 % RING>{});
+    body(kt + 3, IntC<3 % RING>{});
+  }
+  // nkt is a multiple of 8 (k-ranges are whole 128-tiles): no remainder
+
+  // ---- epilogue: per-column sums of squares of the tile (fp64), out[tile row][column]
+  double* red = reinterpret_cast<double*>(lds);      // [WM][128]; the k-loop ended with a barrier
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float v = p.alpha * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 32) red[wm * 128 + col_w + 32 * b + lane] = (double)s;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    double t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) t2 += red[w * 128 + tid];
+    p.out[(long long)tm * p.Mp + col0 + tid] = t2;
+  }
+}
+
+}  // namespace
+
+extern "C" int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, src && dst, "split3: null pointer");
+  GPK_REQUIRE(h, rows >= 1 && cols >= 16 && cols % 16 == 0 && ld >= cols && ld % 4 == 0, "split3: cols must be a multiple of 16");
+  GPK_REQUIRE(h, ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split3: buffers must be 16-byte aligned");
+  const long long n = rows * (cols / 8);
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, (long long)rows,
+                     (long long)cols, (long long)ld, (V16*)dst);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+                                         const void* W3, int64_t Np, const float* Xq, int64_t M, double kss,
+                                         double floor_, float* work, void* work3, double* var) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && W3 && Xq && work && work3 && var, "predict_var_inv_split: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && Np == gpk_padded(N), "predict_var_inv_split: Np must equal gpk_padded(N)");
+  GPK_REQUIRE(h, h->batch == 1, "predict_var_inv_split: not available in batched mode");
+  const int64_t Mp = gpk_padded(M);
+  const int ntm = (int)(Np / 128), ntn = (int)(Mp / 128);
+  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 6 * 128 < (1ll << 31), "predict_var_inv_split: size too large");
+  // Kq (Mp x Np, query-major, k contiguous) = k(Xq, X) in fp32, then its exact three-way bf16 split
+  GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
+  GPK_TRY(gpk_split3(h, work, Mp, Np, Np, work3));
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
+  SParams p;
+  p.A = (const char*)W3; p.B = (const char*)work3; p.out = (double*)partial;
+  p.rsa = Np * 6; p.rsb = Np * 6; p.Mp = Mp;
+  p.ntm = ntm; p.ntn = ntn;
+  p.nst = (int)(((long long)ntm * ntn + 63) / 64);
+  p.alpha = 1.0f;
+  const long long nblocks = (long long)((p.nst + 7) / 8) * 512;
+#ifndef GPK_K5S_WM
+#define GPK_K5S_WM 4
+#endif
+  hipLaunchKernelGGL(k5_split_kernel<GPK_K5S_WM>, dim3((unsigned)nblocks), dim3(GPK_K5S_WM * 128), 0, h->stream, p);
+  GPK_LAUNCH_CHECK(h);
+  GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
+  return gpk_var_finalize(h, var, M, kss, floor_, var);
+}

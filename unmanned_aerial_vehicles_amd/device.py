@@ -404,6 +404,20 @@ class DeviceGP:
                 self._Winv["f64"] = W
         return self._Winv[key]
 
+    def split_inverse_factor(self):
+        """The fp32 inverse factor as three exact bf16 parts per entry (gpk_split3 layout, 6 bytes per entry):
+        the operand of the bf16-pipe variance launch (`method="inverse_split"`)."""
+        torch = _torch()
+        if "split" not in self._Winv:
+            Wf = self.inverse_factor(True)
+            be = self.be
+            W3 = be.empty((self.Np * self.Np * 6,), torch.uint8)
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_split3(be.h, _p(Wf), self.Np, self.Np, self.Np, _p(W3)))
+            self._Winv["split"] = W3
+        return self._Winv["split"]
+
     def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64", method="auto"):
         """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units).
 
@@ -415,8 +429,10 @@ class DeviceGP:
         f32 = dtype in ("float32", np.float32, torch.float32)
         if method == "auto":
             method = "inverse"
-        if method not in ("solve", "inverse"):
-            raise ValueError("method must be 'auto', 'solve' or 'inverse'")
+        if method not in ("solve", "inverse", "inverse_split"):
+            raise ValueError("method must be 'auto', 'solve', 'inverse' or 'inverse_split'")
+        if method == "inverse_split" and not f32:
+            raise ValueError("inverse_split is the fp32 serving form (exact bf16x3 operand split)")
         tdt = torch.float32 if f32 else torch.float64
         es = 4 if f32 else 8
         code = GPK_F32 if f32 else GPK_F64
@@ -426,7 +442,9 @@ class DeviceGP:
         if M == 0:
             return out
         Xd = self._f32_data()["X"] if f32 else self.X
-        if method == "inverse":
+        if method == "inverse_split":
+            W3 = self.split_inverse_factor()
+        elif method == "inverse":
             Wd = self.inverse_factor(f32)
         elif f32:
             c = self._f32_factor()
@@ -436,6 +454,7 @@ class DeviceGP:
         panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * es)) // 128 * 128))
         panel = min(panel, padded(M))
         work = self.be.empty((self.Np * panel,), tdt)
+        work3 = self.be.empty((self.Np * panel * 6,), torch.uint8) if method == "inverse_split" else None
         var = self.be.empty((panel,), torch.float64)
         be = self.be
         lsp = self.ls.ctypes.data_as(_lib._dp)
@@ -443,7 +462,11 @@ class DeviceGP:
             be.bind_stream()
             for m0 in range(0, M, panel):
                 m1 = min(M, m0 + panel)
-                if method == "inverse":
+                if method == "inverse_split":
+                    be.check(be.lib.gpk_predict_var_inv_split(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W3),
+                                                              self.Np, _p(q[m0:m1]), m1 - m0, float(kss), float(floor),
+                                                              _p(work), _p(work3), _p(var)))
+                elif method == "inverse":
                     be.check(be.lib.gpk_predict_var_inv(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Wd),
                                                         self.Np, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
                                                         float(floor), _p(work), _p(var)))
