@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--n-train", type=int, default=65536)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="skip the extra timing of the bf16x3-split variance path")
     ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
                     help="c3 (default, the headline): mean+var for 10 000 queries per GPU per step, weak scaling; "
                          "c4: BASELINE configs[3] - 1 048 576 queries in total sharded over the GPUs, posterior means "
@@ -322,6 +323,39 @@ def main():
                     "note": "PCIe-inclusive: 10 000 x 9 fp32 queries host->HBM, (10 000 x 6) fp64 results HBM->host"}
         assert np.isfinite(res).all()
 
+    # ---------------------------------------------------------------- extra: K5 on the bf16 pipe (exact split)
+    # Not the headline: `value` above is the fp32-MFMA path.  The same variance through six bf16 MFMAs per block
+    # product on operands split exactly into three bf16 parts (fp32 accuracy) is timed beside it.
+    split_info = None
+    if rank == 0 and world == 1 and not c4 and args.var_method == "inverse" and not args.no_split:
+        try:
+            dev.split_inverse_factor()
+            vs = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split")
+            v32 = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse")
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                dev.predict_mean_dev(q32, y_mean, y_std, "float32")
+                dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split")
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e-3)
+            t_split = sorted(ts)[1]
+            split_info = {
+                "what": "mean + variance with the variance GEMM on the bf16 matrix pipe: fp32 operands split exactly "
+                        "into 3 bf16 parts (round to nearest), 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product, "
+                        "fp32 accumulation",
+                "ms_per_step": t_split * 1e3, "predictions_per_s": M / t_split,
+                "fp32_equivalent_TFLOPs": float(N) * N * M / t_split / 1e12,
+                "bf16_mfma_TFLOPs": 6.0 * float(N) * N * M / t_split / 1e12, "bf16_mfma_peak_TFLOPs": 2516.0,
+                "max_abs_var_diff_vs_fp32_mfma_path": float(torch.max(torch.abs(vs - v32))),
+                "var_range": [float(torch.min(v32)), float(torch.max(v32))]}
+            dev._Winv.pop("split", None)
+        except Exception as e:  # noqa: BLE001 - the extra must never take the headline down
+            split_info = {"error": repr(e)}
+
     if rank == 0:
         total_pred = float(M) * world * args.steps
         line = {
@@ -343,6 +377,7 @@ def main():
             "roofline": roof,
             "fit": fit,
             "host_api": host_api,
+            "bf16x3_split": split_info,
         }
         if not args.no_cpu_baseline and world == 1 and not c4:     # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline()

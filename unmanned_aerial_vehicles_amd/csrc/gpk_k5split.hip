@@ -291,7 +291,7 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   p.alpha = 1.0f;
   const long long nblocks = (long long)((p.nst + 7) / 8) * 512;
 #ifndef GPK_K5S_WM
-#define GPK_K5S_WM 4
+#define GPK_K5S_WM 2     // measured at N = 65536, 10 000 queries: 4 waves of 64 x 64: 242.7 ms; 8 waves of 32 x 64: 254.1 ms
 #endif
   hipLaunchKernelGGL(k5_split_kernel<GPK_K5S_WM>, dim3((unsigned)nblocks), dim3(GPK_K5S_WM * 128), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
