@@ -117,9 +117,11 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   // heavy first: row r of the enumeration is tile row ntm-1-r (its k-range is (row + 1) * 128: longest first);
   // every tile of the group runs to the end of the group's longest row, the one enumerated first (W is zero
   // beyond a row's own range for 16 tiles; a group spans at most two bands = 16 tile rows)
-  const int band0 = min(st * 64 / per, nfull);
+  const int band0 = min(st * 64 / per, nfull), band1 = min(min(st * 64 + 63, total - 1) / per, nfull);
   tm = p.ntm - 1 - tm;
-  const int rhi = p.ntm - 1 - band0 * 8;
+  // (narrow grids: a group of 64 tiles spans more than two bands - beyond the 16-tile zero band of W - and every
+  // tile keeps its own k-range)
+  const int rhi = (band1 - band0 <= 1) ? p.ntm - 1 - band0 * 8 : tm;
   const int nkt = (rhi + 1) * 8;                 // k-tiles of 16
 
   const int row0 = tm * 128, col0 = tn * 128;
