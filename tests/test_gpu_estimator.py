@@ -313,6 +313,26 @@ def test_one_call_host_path(csv_data):
         dev.predict_host(Xq[:3, :5], gp._y_train_mean, gp._y_train_std)
 
 
+def test_estimator_split_variance_option(csv_data):
+    """`var_method="inverse_split"` with `predict_dtype="float32"` through the estimator surface: same std as the
+    fp64 estimator within the fp32 tolerance; the fp64 estimator refuses the option at predict time."""
+    from unmanned_aerial_vehicles_amd import GaussianProcessRegressor, RBF, WhiteKernel
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((2500, 9)); Y = np.sin(X[:, :3] * 1.3) + 0.1 * rng.standard_normal((2500, 3))
+    k = lambda: RBF(1.5) + WhiteKernel(0.05)
+    g64 = GaussianProcessRegressor(kernel=k(), alpha=1e-4, normalize_y=True, optimizer=None).fit(X, Y)
+    gsp = GaussianProcessRegressor(kernel=k(), alpha=1e-4, normalize_y=True, optimizer=None, predict_dtype="float32",
+                                   var_method="inverse_split").fit(X, Y)
+    Xq = rng.standard_normal((400, 9))
+    m64, s64 = g64.predict(Xq, return_std=True)
+    msp, ssp = gsp.predict(Xq, return_std=True)
+    assert np.max(np.abs(msp - m64)) < 1e-4 * np.max(np.abs(m64))
+    assert np.max(np.abs(ssp - s64) / s64) < 1e-3
+    bad = GaussianProcessRegressor(kernel=k(), alpha=1e-4, optimizer=None, var_method="inverse_split").fit(X, Y)
+    with pytest.raises(ValueError):
+        bad.predict(Xq, return_std=True)
+
+
 def test_baseline_size_properties():
     """BASELINE.json's full size, N_train = 65536 (D = 9, P = 3): size-independent properties of the whole
     path, none of which needs the CPU oracle at that size.

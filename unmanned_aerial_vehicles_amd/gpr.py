@@ -53,7 +53,7 @@ class GaussianProcessRegressor:
         self.random_state = random_state
         self.device = device
         self.predict_dtype = predict_dtype
-        self.var_method = var_method      # 'auto' | 'inverse' | 'solve' (see DeviceGP.predict_var_dev)
+        self.var_method = var_method      # 'auto' | 'inverse' | 'solve' | 'inverse_split' (fp32 only): DeviceGP.predict_var_dev
         self._dev = None
 
     # ------------------------------------------------------------------ fit
