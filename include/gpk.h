@@ -160,8 +160,8 @@ int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int6
 
 /* K5 on the bf16 matrix pipe at fp32 accuracy (exact operand split).
  * gpk_split3: src (dev rows x ld fp32, cols % 16 == 0) -> dst (dev, rows * cols * 6 bytes): every fp32 value
- * as three bf16 parts x = x0 + x1 + x2 (8 significant bits each, by truncation: the sum is exact), stored per
- * row as 16-byte chunks [k16 block][half][part] (96 bytes per 16 columns).
+ * as three bf16 parts x = x0 + x1 + x2 (8 significant bits each, rounded to nearest: the sum is exact), stored as
+ * 16-byte chunks [row / 4][k16 block][row % 4][half][part] (rows % 4 == 0; 96 bytes per row and 16 columns).
  * gpk_predict_var_inv_split: the same result as gpk_predict_var_inv(GPK_F32, ...) with W3 = gpk_split3 of the
  * fp32 inverse factor (gpk_tril_to_f32 output, Np x Np): one launch whose 32 x 32 x 16 block products are six
  * v_mfma_f32_32x32x16_bf16 each (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0; exact bf16 products, fp32

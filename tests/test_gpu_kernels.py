@@ -316,10 +316,10 @@ def test_trtri_wtw_super_tile_sizes(be, Np):
 
 def test_split3_is_exact(be):
     """gpk_split3: every fp32 value becomes three bf16 parts whose sum is the value exactly, laid out as
-    [k16 block][half][part] 16-byte chunks."""
+    [row / 4][k16 block][row % 4][half][part] 16-byte chunks."""
     import torch
     from unmanned_aerial_vehicles_amd import _lib  # noqa: F401
-    rows, cols = 37, 64
+    rows, cols = 36, 64
     g = torch.Generator(device="cpu").manual_seed(11)
     src = torch.randn((rows, cols), generator=g) * torch.exp(8.0 * torch.randn((rows, cols), generator=g))
     src[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-30, 65504.0, 1.0 + 2.0 ** -23, -(2.0 ** -100)])   # normal range
@@ -327,7 +327,8 @@ def test_split3_is_exact(be):
     dst = torch.zeros((rows * cols * 6,), dtype=torch.uint8, device=be.device)
     be.bind_stream()
     be.check(be.lib.gpk_split3(be.h, _p(sd), rows, cols, cols, _p(dst)))
-    raw = dst.cpu().numpy().view(np.uint16).reshape(rows, cols // 16, 2, 3, 8)      # [row][kb][h][part][j]
+    raw = dst.cpu().numpy().view(np.uint16).reshape(rows // 4, cols // 16, 4, 2, 3, 8)   # [quad][kb][row % 4][h][part][j]
+    raw = np.moveaxis(raw, 2, 1).reshape(rows, cols // 16, 2, 3, 8)                 # -> [row][kb][h][part][j]
     parts = (raw.astype(np.uint32) << 16).view(np.float32)                          # bf16 -> fp32 (exact)
     total = parts[..., 0, :].astype(np.float64) + parts[..., 1, :].astype(np.float64) + parts[..., 2, :].astype(np.float64)
     back = total.reshape(rows, cols // 16, 16).reshape(rows, cols)                  # k = 16 kb + 8 h + j

@@ -5,9 +5,11 @@
 // an fp32 FMA).  The fp32 MFMA runs at the vector rate (157 TF); the bf16 pipe is 16x faster, so six instructions
 // per fp32-equivalent product raise the ceiling of this launch by 16/6 = 2.7x.
 //
-// Operand layout (gpk_split3): row-major rows of 16-byte chunks [k16 block][half h][part s] - the eight bf16 of
-// part s for k = 16 kb + 8 h .. + 7 - so that one k-tile of 16 is 96 contiguous bytes per row (consecutive lanes
-// fetch consecutive chunks: a 144-byte-row LDS image fed by 32-byte pieces per row was 35 % slower) and a lane's
+// Operand layout (gpk_split3): 16-byte chunks [row / 4][k16 block][row % 4][half h][part s] - the eight bf16 of
+// part s for k = 16 kb + 8 h .. + 7 - so that one k-tile of 16 of four consecutive rows is 384 contiguous bytes =
+// three whole cache lines (consecutive lanes fetch consecutive chunks, a wave instruction touches 8 lines; with
+// plain row-major 96-byte pieces it touched 11-22 partial lines, and variants that fetched 16- or 32-byte pieces per
+// row were 20-45 % slower: the fetch granularity is what this kernel is most sensitive to) and a lane's
 // MFMA fragment (row r = lane & 31, k half h = lane >> 5) is one ds_read_b128 per part.  LDS rows are padded to
 // 112 bytes (28 dwords = 4 x odd: conflict-free b128 reads over 8 consecutive rows).
 //
@@ -26,7 +28,7 @@ typedef unsigned int V16 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 template <int V> struct IntC { static constexpr int value = V; };
 
-constexpr int ROWB = 96;       // bytes of one k-tile (16 k) of one row: 2 halves x 3 parts x 16 B
+constexpr int ROWB = 384;      // bytes of one k-tile (16 k) of a quad of rows: 4 rows x 2 halves x 3 parts x 16 B
 constexpr int LROW = 112;      // padded LDS row
 constexpr int OPB = 128 * LROW;   // one operand k-tile in LDS
 
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
     f[1][j] = (a1 >> 16) | b1;
     f[2][j] = (a2 >> 16) | (b2 & 0xffff0000u);
   }
-  V16* d = dst + (row * hc + hb) * 3;
+  // chunk order: [row / 4][k16 block][row % 4][half][part]: the k-tile of four consecutive rows is 384 contiguous bytes
+  V16* d = dst + (((row >> 2) * (hc >> 1) + (hb >> 1)) * 4 + (row & 3)) * 6 + (hb & 1) * 3;
   d[0] = f[0]; d[1] = f[1]; d[2] = f[2];
 }
 
@@ -76,7 +79,7 @@ struct SParams {
   const char* A;        // W, split layout, Np rows
   const char* B;        // Kq, split layout, Mp rows
   double* out;          // [ntm][Mp] partial column sums of squares
-  long long rsa, rsb;   // row strides in bytes (Np * 6)
+  long long rsa, rsb;   // bytes between consecutive quads of rows (Np * 24)
   long long Mp;
   int ntm, ntn, nst;
   float alpha;
@@ -142,11 +145,11 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
     const int g = tid + NT * q;
     isb[q] = __builtin_amdgcn_readfirstlane(g >= 768 ? 1 : 0) != 0;
     const int c = isb[q] ? g - 768 : g, row = c / 6, w = c - row * 6;
-    goff[q] = (unsigned)((long long)row * p.rsa + w * 16);
+    goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * 6 + w) * 16);     // rsa: bytes between row quads
     lofs[q] = (isb[q] ? OPB : 0) + row * LROW + w * 16;
   }
-  const char* ua = p.A + (long long)row0 * p.rsa;
-  const char* ub = p.B + (long long)col0 * p.rsb;
+  const char* ua = p.A + (long long)(row0 >> 2) * p.rsa;
+  const char* ub = p.B + (long long)(col0 >> 2) * p.rsb;
   // Register ring of RING k-tiles in flight: the fetch of k-tile kt+1+RING is issued when k-tile kt+1 leaves its
   // ring slot for LDS.  The loop is unrolled by 4: slot and LDS buffer indices are constants.
 #ifndef GPK_K5S_SCHED
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
 extern "C" int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst) {
   if (!h) return GPK_BAD_ARG;
   GPK_REQUIRE(h, src && dst, "split3: null pointer");
-  GPK_REQUIRE(h, rows >= 1 && cols >= 16 && cols % 16 == 0 && ld >= cols && ld % 4 == 0, "split3: cols must be a multiple of 16");
+  GPK_REQUIRE(h, rows >= 4 && rows % 4 == 0 && cols >= 16 && cols % 16 == 0 && ld >= cols && ld % 4 == 0,
+              "split3: rows must be a multiple of 4 and cols a multiple of 16");
   GPK_REQUIRE(h, ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split3: buffers must be 16-byte aligned");
   const long long n = rows * (cols / 8);
   hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, (long long)rows,
@@ -287,7 +291,7 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
   SParams p;
   p.A = (const char*)W3; p.B = (const char*)work3; p.out = (double*)partial;
-  p.rsa = Np * 6; p.rsb = Np * 6; p.Mp = Mp;
+  p.rsa = Np * 24; p.rsb = Np * 24; p.Mp = Mp;      // bytes between consecutive quads of rows
   p.ntm = ntm; p.ntn = ntn;
   p.nst = (int)(((long long)ntm * ntn + 63) / 64);
   p.alpha = 1.0f;
