@@ -175,33 +175,11 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) *reinterpret_cast<V16*>(buf + lofs[q]) = rr[sl][q];
   };
-  fetch(0, IntC<0>{});
-  stage(lds, IntC<0>{});
-  fetch(1, IntC<1 % RING>{});
-  if constexpr (RING >= 2) fetch(2, IntC<2 % RING>{});
-  if constexpr (RING >= 3) fetch(3, IntC<3 % RING>{});
-  if constexpr (RING >= 4) { fetch(4, IntC<0>{}); }
-  __syncthreads();
+#ifndef GPK_K5S_FPRE
+#define GPK_K5S_FPRE 1
+#endif
   const int fr = lane & 31, fh = lane >> 5;
-  // iteration kt (kt % RING == KS): k-tile kt+1 goes from ring slot (KS+1) % RING to LDS buffer (kt+1) & 1, that
-  // slot is refilled with k-tile kt+1+RING, and k-tile kt is multiplied out of LDS buffer kt & 1
-  auto body = [&](int kt, auto ksc) {
-    constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
-    stage(lds + (cur ^ 1) * 2 * OPB, IntC<sl>{});
-    fetch(kt + 1 + RING, IntC<sl>{});
-    const char* la = lds + cur * 2 * OPB;
-    const char* lb = la + OPB;
-    bf16x8 af[AB][3], bf[2][3];
-#pragma unroll
-    for (int a = 0; a < AB; ++a)
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(la + (row_w + 32 * a + fr) * LROW + (fh * 3 + s) * 16));
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lb + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
+  auto mfmas = [&](const bf16x8 (&af)[AB][3], const bf16x8 (&bf)[2][3]) {
     // smallest terms first
 #pragma unroll
     for (int a = 0; a < AB; ++a)
@@ -216,6 +194,69 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
         acc[a][b] = c;
       }
+  };
+  auto frags = [&](const char* buf, bf16x8 (&af)[AB][3], bf16x8 (&bf)[2][3]) {
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + (row_w + 32 * a + fr) * LROW + (fh * 3 + s) * 16));
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + OPB + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
+  };
+#if GPK_K5S_FPRE
+  // Fragments one k-tile ahead: while the MFMAs of k-tile kt run out of registers F[kt & 1], the fragments of k-tile
+  // kt+1 are read from LDS buffer (kt+1) & 1 into F[(kt+1) & 1] and k-tile kt+2 is written into LDS buffer kt & 1
+  // (its previous content, k-tile kt, was read during iteration kt-1; the barrier at the end of each iteration
+  // separates the two).  No MFMA waits for LDS.
+  static_assert(RING == 2, "the fragment-prefetch pipeline is written for a ring of two k-tiles");
+  bf16x8 FA[2][AB][3], FB[2][2][3];
+  fetch(0, IntC<0>{});
+  stage(lds, IntC<0>{});
+  fetch(1, IntC<1>{});
+  stage(lds + 2 * OPB, IntC<1>{});
+  fetch(2, IntC<0>{});
+  fetch(3, IntC<1>{});
+  __syncthreads();
+  frags(lds, FA[0], FB[0]);
+  __syncthreads();
+  auto body = [&](int kt, auto ksc) {
+    constexpr int KS = decltype(ksc)::value, cur = KS & 1;
+    stage(lds + cur * 2 * OPB, IntC<cur>{});            // k-tile kt+2 (ring slot (kt+2) % 2 = cur)
+    fetch(kt + 4, IntC<cur>{});
+    frags(lds + (cur ^ 1) * 2 * OPB, FA[cur ^ 1], FB[cur ^ 1]);
+    mfmas(FA[cur], FB[cur]);
+#if GPK_K5S_SCHED
+    __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 12 * AB / NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (3 * AB + 6) / NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#endif
+    __syncthreads();
+  };
+#else
+  fetch(0, IntC<0>{});
+  stage(lds, IntC<0>{});
+  fetch(1, IntC<1 % RING>{});
+  if constexpr (RING >= 2) fetch(2, IntC<2 % RING>{});
+  if constexpr (RING >= 3) fetch(3, IntC<3 % RING>{});
+  if constexpr (RING >= 4) { fetch(4, IntC<0>{}); }
+  __syncthreads();
+  // iteration kt (kt % RING == KS): k-tile kt+1 goes from ring slot (KS+1) % RING to LDS buffer (kt+1) & 1, that
+  // slot is refilled with k-tile kt+1+RING, and k-tile kt is multiplied out of LDS buffer kt & 1
+  auto body = [&](int kt, auto ksc) {
+    constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
+    stage(lds + (cur ^ 1) * 2 * OPB, IntC<sl>{});
+    fetch(kt + 1 + RING, IntC<sl>{});
+    bf16x8 af[AB][3], bf[2][3];
+    frags(lds + cur * 2 * OPB, af, bf);
+    mfmas(af, bf);
 #if GPK_K5S_SCHED
     // issue order: LDS writes of the next k-tile, all twelve fragment reads, then the MFMAs with the six
     // buffer loads spread among them (the scheduler otherwise trickles the reads between MFMAs and waits five times)
@@ -229,6 +270,7 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
 #endif
     __syncthreads();
   };
+#endif
   int kt = 0;
   for (; kt + 3 < nkt; kt += 4) {
     body(kt, IntC<0 % RING>{});
