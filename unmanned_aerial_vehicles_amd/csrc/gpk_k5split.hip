@@ -30,7 +30,6 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 constexpr int ROWB = 384;      // bytes of one k-tile (16 k) of a quad of rows: 4 rows x 2 halves x 3 parts x 16 B
 constexpr int LROW = 112;      // padded LDS row
-constexpr int OPB = 128 * LROW;   // one operand k-tile in LDS
 
 // bf16 part of a finite fp32 value, rounded to nearest even (as bits in the upper half of a dword)
 __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
@@ -92,42 +91,49 @@ __device__ __forceinline__ void load3(const char* __restrict__ ubase, const unsi
   for (int p = 0; p < NP; ++p) r[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], 0, 0);
 }
 
-// WM wave rows x 2 wave columns per workgroup: WM = 2 -> 4 waves of 64 x 64, WM = 4 -> 8 waves of 32 x 64
-template <int WM>
-__global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * OPB];       // 2 stages x [A | B]
-  constexpr int NT = WM * 128, AB = 4 / WM, NQ = 1536 / NT;        // threads, 32-row blocks per wave, chunks per thread
+// WR wave rows x 2 wave columns of 64 x 64 per workgroup: WR = 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU;
+// WR = 4 -> 256 x 128 tile, 8 waves, 1 workgroup per CU (25 % less operand staging per MFMA)
+template <int WR>
+__global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
+  constexpr int TMR = 64 * WR;                                     // tile rows
+  constexpr int SSZ = (TMR + 128) * LROW;                          // one LDS stage: [A k-tile | B k-tile]
+  constexpr int BOFF = TMR * LROW;                                 // B inside a stage
+  __shared__ __attribute__((aligned(16))) char lds[2 * SSZ];
+  constexpr int NT = WR * 128, AB = 2, NCH = (TMR + 128) * 6, NQ = (NCH + NT - 1) / NT;   // threads, blocks, chunks
+  constexpr int GSZ = WR == 2 ? 64 : 32;                           // resident workgroups per XCD = tiles per group
+  constexpr int BH = 1024 / TMR;                                   // band height in tile rows (1024 matrix rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int row_w = wm * (128 / WM), col_w = wn * 64;
+  const int row_w = wm * 64, col_w = wn * 64;
 
-  // ---- tile mapping: bands of 8 tile rows walked column by column in groups of 64 tiles, serpentine over XCDs
+  // ---- tile mapping: bands of 1024 rows walked column by column in groups of GSZ tiles, serpentine over XCDs
+  const int ntm = p.ntm * 128 / TMR;                               // tile rows of this configuration
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int grp = j >> 6, slot = j & 63;
+  const int grp = j / GSZ, slot = j - grp * GSZ;
   const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
   if (st >= p.nst) return;
-  const int per = 8 * p.ntn, nfull = p.ntm / 8, hlast = p.ntm - nfull * 8, total = p.ntm * p.ntn;
+  const int per = BH * p.ntn, nfull = ntm / BH, hlast = ntm - nfull * BH, total = ntm * p.ntn;
   auto place = [&](int t, int& row, int& col, int& band) {
     band = min(t / per, nfull);
-    const int idx = t - band * per, hh = band < nfull ? 8 : hlast;
+    const int idx = t - band * per, hh = band < nfull ? BH : hlast;
     col = idx / hh;
-    row = band * 8 + (idx - col * hh);
+    row = band * BH + (idx - col * hh);
   };
-  const int t = st * 64 + slot;
+  const int t = st * GSZ + slot;
   if (t >= total) return;
   int tm, tn, band;
   place(t, tm, tn, band);
-  // heavy first: row r of the enumeration is tile row ntm-1-r (its k-range is (row + 1) * 128: longest first);
+  // heavy first: row r of the enumeration is tile row ntm-1-r (its k-range is (row + 1) * TMR: longest first);
   // every tile of the group runs to the end of the group's longest row, the one enumerated first (W is zero
-  // beyond a row's own range for 16 tiles; a group spans at most two bands = 16 tile rows)
-  const int band0 = min(st * 64 / per, nfull), band1 = min(min(st * 64 + 63, total - 1) / per, nfull);
-  tm = p.ntm - 1 - tm;
-  // (narrow grids: a group of 64 tiles spans more than two bands - beyond the 16-tile zero band of W - and every
-  // tile keeps its own k-range)
-  const int rhi = (band1 - band0 <= 1) ? p.ntm - 1 - band0 * 8 : tm;
-  const int nkt = (rhi + 1) * 8;                 // k-tiles of 16
+  // beyond a row's own range for 16 tiles of 128; a group spans at most two bands = 2048 rows)
+  const int band0 = min(st * GSZ / per, nfull), band1 = min(min(st * GSZ + GSZ - 1, total - 1) / per, nfull);
+  tm = ntm - 1 - tm;
+  // (narrow grids: a group spans more than two bands - beyond the zero band of W - and every tile keeps its own
+  // k-range)
+  const int rhi = (band1 - band0 <= 1) ? ntm - 1 - band0 * BH : tm;
+  const int nkt = (rhi + 1) * (TMR / 16);        // k-tiles of 16
 
-  const int row0 = tm * 128, col0 = tn * 128;
+  const int row0 = tm * TMR, col0 = tn * 128;
   f16v acc[AB][2];
 #pragma unroll
   for (int a = 0; a < AB; ++a)
@@ -136,17 +142,18 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  // a k-tile is 768 chunks of 16 B per operand; chunk g = tid + NT q of the 1536 (A first, then B) is this thread's
-  // q-th; which operand it belongs to is wave-uniform
+  // a k-tile is TMR * 6 chunks of 16 B of A and 768 of B; chunk g = tid + NT q of them (A first) is this thread's
+  // q-th; which operand it belongs to - and whether it exists at all - is wave-uniform
   unsigned goff[NQ], lofs[NQ];
-  bool isb[NQ];
+  bool isb[NQ], live[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int g = tid + NT * q;
-    isb[q] = __builtin_amdgcn_readfirstlane(g >= 768 ? 1 : 0) != 0;
-    const int c = isb[q] ? g - 768 : g, row = c / 6, w = c - row * 6;
+    live[q] = __builtin_amdgcn_readfirstlane(g < NCH ? 1 : 0) != 0;
+    isb[q] = __builtin_amdgcn_readfirstlane(g >= TMR * 6 ? 1 : 0) != 0;
+    const int c = live[q] ? (isb[q] ? g - TMR * 6 : g) : 0, row = c / 6, w = c - row * 6;
     goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * 6 + w) * 16);     // rsa: bytes between row quads
-    lofs[q] = (isb[q] ? OPB : 0) + row * LROW + w * 16;
+    lofs[q] = (isb[q] ? BOFF : 0) + row * LROW + w * 16;
   }
   const char* ua = p.A + (long long)(row0 >> 2) * p.rsa;
   const char* ub = p.B + (long long)(col0 >> 2) * p.rsb;
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
     const long long ko = (long long)min(tile, nkt - 1) * ROWB;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      if (NCH % NT != 0 && !live[q]) continue;      // (only the last chunk of the 256-row configuration can be absent)
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((isb[q] ? ub : ua) + ko), 0, 0x7fffffff, 0x00020000);
       rr[sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[q], 0, 0);
@@ -173,7 +181,8 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   auto stage = [&](char* buf, auto slotc) {
     constexpr int sl = decltype(slotc)::value;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) *reinterpret_cast<V16*>(buf + lofs[q]) = rr[sl][q];
+    for (int q = 0; q < NQ; ++q)
+      if (NCH % NT == 0 || live[q]) *reinterpret_cast<V16*>(buf + lofs[q]) = rr[sl][q];
   };
 #ifndef GPK_K5S_FPRE
 #define GPK_K5S_FPRE 1
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int s = 0; s < 3; ++s)
-        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + OPB + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
+        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + BOFF + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
   };
 #if GPK_K5S_FPRE
   // Fragments one k-tile ahead: while the MFMAs of k-tile kt run out of registers F[kt & 1], the fragments of k-tile
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   fetch(0, IntC<0>{});
   stage(lds, IntC<0>{});
   fetch(1, IntC<1>{});
-  stage(lds + 2 * OPB, IntC<1>{});
+  stage(lds + SSZ, IntC<1>{});
   fetch(2, IntC<0>{});
   fetch(3, IntC<1>{});
   __syncthreads();
@@ -225,9 +234,9 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   __syncthreads();
   auto body = [&](int kt, auto ksc) {
     constexpr int KS = decltype(ksc)::value, cur = KS & 1;
-    stage(lds + cur * 2 * OPB, IntC<cur>{});            // k-tile kt+2 (ring slot (kt+2) % 2 = cur)
+    stage(lds + cur * SSZ, IntC<cur>{});            // k-tile kt+2 (ring slot (kt+2) % 2 = cur)
     fetch(kt + 4, IntC<cur>{});
-    frags(lds + (cur ^ 1) * 2 * OPB, FA[cur ^ 1], FB[cur ^ 1]);
+    frags(lds + (cur ^ 1) * SSZ, FA[cur ^ 1], FB[cur ^ 1]);
     mfmas(FA[cur], FB[cur]);
 #if GPK_K5S_SCHED
     __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
@@ -252,10 +261,10 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   // slot is refilled with k-tile kt+1+RING, and k-tile kt is multiplied out of LDS buffer kt & 1
   auto body = [&](int kt, auto ksc) {
     constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
-    stage(lds + (cur ^ 1) * 2 * OPB, IntC<sl>{});
+    stage(lds + (cur ^ 1) * SSZ, IntC<sl>{});
     fetch(kt + 1 + RING, IntC<sl>{});
     bf16x8 af[AB][3], bf[2][3];
-    frags(lds + cur * 2 * OPB, af, bf);
+    frags(lds + cur * SSZ, af, bf);
     mfmas(af, bf);
 #if GPK_K5S_SCHED
     // issue order: LDS writes of the next k-tile, all twelve fragment reads, then the MFMAs with the six
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   // nkt is a multiple of 8 (k-ranges are whole 128-tiles): no remainder
 
   // ---- epilogue: per-column sums of squares of the tile (fp64), out[tile row][column]
-  double* red = reinterpret_cast<double*>(lds);      // [WM][128]; the k-loop ended with a barrier
+  double* red = reinterpret_cast<double*>(lds);      // [WR][128]; the k-loop ended with a barrier
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     float s = 0.f;
@@ -296,8 +305,8 @@ __global__ __launch_bounds__(WM * 128, 2) void k5_split_kernel(SParams p) {
   if (tid < 128) {
     double t2 = 0.0;
 #pragma unroll
-    for (int w = 0; w < WM; ++w) t2 += red[w * 128 + tid];
-    p.out[(long long)tm * p.Mp + col0 + tid] = t2;
+    for (int w = 0; w < WR; ++w) t2 += red[w * 128 + tid];
+    p.out[(long long)tm * p.Mp + col0 + tid] = t2;      // one partial row per tile row of TMR matrix rows
   }
 }
 
@@ -329,20 +338,24 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   // Kq (Mp x Np, query-major, k contiguous) = k(Xq, X) in fp32, then its exact three-way bf16 split
   GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
   GPK_TRY(gpk_split3(h, work, Mp, Np, Np, work3));
+#ifndef GPK_K5S_WR
+#define GPK_K5S_WR 4
+#endif
+  // 256 x 128 tiles (8 waves, one workgroup per CU) when Np is a multiple of 256, else 128 x 128 (4 waves, two per CU)
+  const int wr = (GPK_K5S_WR == 4 && Np % 256 == 0) ? 4 : 2;
+  const int ntmT = (int)(Np / (64 * wr)), gsz = wr == 2 ? 64 : 32;
   void* partial = nullptr;
-  GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
+  GPK_TRY(gpk_scratch(h, (size_t)ntmT * Mp * sizeof(double), &partial));
   SParams p;
   p.A = (const char*)W3; p.B = (const char*)work3; p.out = (double*)partial;
   p.rsa = Np * 24; p.rsb = Np * 24; p.Mp = Mp;      // bytes between consecutive quads of rows
   p.ntm = ntm; p.ntn = ntn;
-  p.nst = (int)(((long long)ntm * ntn + 63) / 64);
+  p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
   p.alpha = 1.0f;
-  const long long nblocks = (long long)((p.nst + 7) / 8) * 512;
-#ifndef GPK_K5S_WM
-#define GPK_K5S_WM 2     // measured at N = 65536, 10 000 queries: 4 waves of 64 x 64: 242.7 ms; 8 waves of 32 x 64: 254.1 ms
-#endif
-  hipLaunchKernelGGL(k5_split_kernel<GPK_K5S_WM>, dim3((unsigned)nblocks), dim3(GPK_K5S_WM * 128), 0, h->stream, p);
+  const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
+  if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  else hipLaunchKernelGGL(k5_split_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
-  GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
+  GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntmT, Mp, var));
   return gpk_var_finalize(h, var, M, kss, floor_, var);
 }
