@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: random (N, D, P, M, hyper-parameters, ARD or isotropic, predict dtype, variance
+method) through the estimator seam against the CPU oracle.  Not part of the test suite (the suite pins fixed
+cases); this is the tool that hunts for size-dependent indexing mistakes (tile edges, zero band, super-tile
+gating, ragged query batches).  `FUZZ_CASES` (default 150), `FUZZ_SEED`, `FUZZ_MAX_N` (default 3000)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+from unmanned_aerial_vehicles_amd import RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel  # noqa: E402
+
+cases = int(os.environ.get("FUZZ_CASES", "150"))
+seed = int(os.environ.get("FUZZ_SEED", "0"))
+max_n = int(os.environ.get("FUZZ_MAX_N", "3000"))
+rng = np.random.default_rng(seed)
+EDGE = [4095, 4096, 4097, 3071, 3072, 3200, 4224, 5120, 6144, 1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 1023, 1024, 1025,
+        2047, 2048, 2049]
+
+
+def pick(hi):
+    if rng.random() < 0.5:
+        return int(rng.choice([e for e in EDGE if e <= hi]))
+    return int(rng.integers(1, hi + 1))
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+bad = 0
+t0 = time.time()
+for c in range(cases):
+    N, M = pick(max_n), pick(max_n)
+    D, P = int(rng.integers(1, 17)), int(rng.integers(1, 13))
+    ard = rng.random() < 0.4
+    ls = np.exp(rng.uniform(np.log(0.6), np.log(3.0), D)) * np.sqrt(D) / 2 if ard else float(np.exp(rng.uniform(np.log(0.6), np.log(3.0))) * np.sqrt(D) / 2)
+    sf2 = float(np.exp(rng.uniform(-1, 1))) if rng.random() < 0.5 else 1.0
+    noise = float(np.exp(rng.uniform(np.log(1e-3), np.log(0.3))))
+    normalize = bool(rng.random() < 0.5)
+    pd = "float32" if rng.random() < 0.4 else "float64"
+    vm = str(rng.choice(["auto", "inverse", "solve"] + (["inverse_split"] if pd == "float32" else [])))
+    X = rng.standard_normal((N, D))
+    Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+    Xq = rng.standard_normal((M, D)) * rng.choice([0.5, 1.0, 2.0])
+    kern = RBF(ls) + WhiteKernel(noise)
+    if sf2 != 1.0:
+        kern = ConstantKernel(sf2) * RBF(ls) + WhiteKernel(noise)
+    tag = f"case {c}: N={N} M={M} D={D} P={P} ard={ard} sf2={sf2:.3g} noise={noise:.3g} norm={normalize} {pd} {vm}"
+    try:
+        g = GaussianProcessRegressor(kernel=kern, alpha=1e-8, normalize_y=normalize, optimizer=None, predict_dtype=pd,
+                                     var_method=vm).fit(X, Y)
+        mean, std = g.predict(Xq, return_std=True)
+        mean_only = g.predict(Xq)
+        lml = g.log_marginal_likelihood_value_
+        lml2, grad = g.log_marginal_likelihood(g.kernel_.theta, eval_gradient=True)
+    except Exception as e:  # noqa: BLE001
+        print("EXC ", tag, repr(e), flush=True); bad += 1
+        continue
+    st = O.fit_fixed(X, Y, ls, sf2, noise, 1e-8, normalize)
+    om, os_ = O.predict(st, Xq, return_std=True)
+    olml = O.log_marginal_likelihood(st)
+    ograd = O.lml_gradient(st, ard=ard)
+    mean, std, om, os_ = (np.asarray(a).reshape(M, -1) for a in (mean, std, om, os_))
+    e_mean, e_std = rel(mean, om), rel(std, os_)
+    e_lml = abs(lml - olml) / abs(olml)
+    # the oracle's gradient covers (sf2?, ls..., noise) in the kernel's own theta order when all are free
+    grad = np.asarray(grad)[1:] if len(grad) == len(ograd) + 1 else np.asarray(grad)    # leading ConstantKernel term: not in the oracle
+    e_grad = rel(grad, np.asarray(ograd)) if np.shape(grad) == np.shape(ograd) else float("inf")
+    # fp32 mean: every term K*_mj alpha_j carries a few fp32 roundings, so the bound scales with sum_j |K*_mj alpha_j|
+    cond = float(np.max(np.abs(O.rbf_cross(Xq, st.X, st.length_scale, st.signal_variance)) @ np.abs(st.alpha) * st.y_std) / max(np.max(np.abs(om)), 1e-300))
+    tol_m, tol_s = (max(2e-4, 5e-7 * cond), 2e-3) if pd == "float32" else (1e-8, 1e-7)
+    ok = (e_mean < tol_m and e_std < tol_s and e_lml < 1e-9 and abs(lml2 - lml) <= 1e-9 * abs(lml) and not (e_grad > 1e-6)
+          and np.array_equal(np.asarray(mean_only).reshape(M, -1), mean))
+    if not ok:
+        bad += 1
+    print(("ok   " if ok else "FAIL ") + tag + f"  mean {e_mean:.1e} std {e_std:.1e} lml {e_lml:.1e} grad {e_grad:.1e}", flush=True)
+print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
