@@ -123,7 +123,9 @@ def test_model_seam_at_reference_theta(csv_data, ka):
     Xr = np.stack([ka["ka3_hor_X"]] * 3)
     Ur = np.stack([ka["ka3_hor_U"]] * 3)
     Dr = gp.build_gp_residuals(Xr, Ur, float(ka["ka3_hor_dt"]))
-    assert Dr.shape == (3, 6, 25) and all(np.array_equal(Dr[r], D) for r in range(3))
+    # (the 75-row batch takes the general kernels, the 25-row one the small-batch kernels: same numbers to round-off,
+    # and the copies inside one batch are bit-identical)
+    assert Dr.shape == (3, 6, 25) and all(np.array_equal(Dr[r], Dr[0]) for r in range(3)) and relerr(Dr[0], D) < 1e-13
     # untrained fallbacks never raise (simple_gp.py:189-190)
     g0 = SimpleQuadrotorGP()
     m0, v0 = g0.predict_residual(np.zeros(6), np.zeros(4))
@@ -311,6 +313,34 @@ def test_one_call_host_path(csv_data):
     assert np.max(np.abs(var - vd)) < 1e-12 and np.all(var >= 0.0)
     with pytest.raises(ValueError):
         dev.predict_host(Xq[:3, :5], gp._y_train_mean, gp._y_train_std)
+
+
+def test_small_batch_kernels_vs_oracle():
+    """Up to 32 fp64 queries take the two-launch kernels of gpk_small.hip (K* + mean shares, then 16 rows of the
+    inverse factor per workgroup on the fp64 MFMA; the last workgroup of each launch adds the shares).  Ragged
+    sizes on both sides of every tile edge, one and two 16-query blocks, repeated calls (the ticket counters must
+    come back to zero), against the oracle."""
+    from unmanned_aerial_vehicles_amd import GaussianProcessRegressor, RBF, ConstantKernel, WhiteKernel
+    rng = np.random.default_rng(21)
+    for N, D, P, sf2 in ((5, 1, 1, 1.0), (100, 3, 2, 2.5), (1000, 10, 6, 1.0), (1025, 16, 12, 0.7), (3000, 9, 3, 1.0)):
+        X = rng.standard_normal((N, D)); Y = np.sin(X @ rng.standard_normal((D, P))) + 0.05 * rng.standard_normal((N, P))
+        ls = np.exp(rng.uniform(-0.2, 0.6, D)) * np.sqrt(D) / 2
+        kern = RBF(ls) + WhiteKernel(0.05) if sf2 == 1.0 else ConstantKernel(sf2) * RBF(ls) + WhiteKernel(0.05)
+        gp = GaussianProcessRegressor(kernel=kern, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, Y)
+        st = O.fit_fixed(X, Y, ls, sf2, 0.05, 1e-6, True)
+        for M in (1, 2, 15, 16, 17, 25, 32):
+            Xq = rng.standard_normal((M, D)) * 1.2
+            assert gp._dev.host_path_ok(M, True)
+            for _ in range(2):
+                mean, std = gp.predict(Xq, return_std=True)
+                om, os_ = O.predict(st, Xq, return_std=True)
+                assert relerr(np.reshape(mean, (M, P)), om) < 1e-10, (N, D, P, M)
+                assert relerr(np.reshape(std, (M, P)), os_) < 1e-9, (N, D, P, M)
+            assert np.array_equal(gp.predict(Xq), mean)
+    # far-away queries: the variance is the prior's, the mean the training mean; a query on a training point: clipped at >= 0
+    gp = GaussianProcessRegressor(kernel=RBF(1.0) + WhiteKernel(1e-6), alpha=0.0, normalize_y=False, optimizer=None).fit(X[:200], Y[:200])
+    mean, std = gp.predict(np.vstack([X[:3], 50.0 + X[:2]]), return_std=True)
+    assert np.all(std[:3] >= 0) and np.all(std[:3] < 2e-3) and np.allclose(std[3:], np.sqrt(1.0 + 1e-6)) and np.allclose(mean[3:], 0.0)
 
 
 def test_estimator_split_variance_option(csv_data):

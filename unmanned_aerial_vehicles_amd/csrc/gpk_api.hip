@@ -18,6 +18,8 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&h->d_info, GPK_MAX_BATCH * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->d_small, 4096) != hipSuccess ||
+      hipMalloc((void**)&h->d_count, 2 * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(h->d_count, 0, 2 * sizeof(unsigned)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_small, 4096, hipHostMallocDefault) != hipSuccess) {
     delete h;
     return GPK_HIP_ERROR;
@@ -27,6 +29,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
   if (const char* e = getenv("GPK_K5_SUPER")) h->k5_super = atoi(e);
+  if (const char* e = getenv("GPK_SMALL_PATH")) h->small_path = atoi(e);
   if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
   *out = h;
   return GPK_OK;
@@ -39,6 +42,7 @@ extern "C" void gpk_destroy(gpk_handle h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_small) (void)hipFree(h->d_small);
+  if (h->d_count) (void)hipFree(h->d_count);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->serve_dev) (void)hipFree(h->serve_dev);
   if (h->serve_host) (void)hipHostFree(h->serve_host);
@@ -155,11 +159,14 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
   GPK_REQUIRE(h, !var_host || (W && Np == gpk_padded(N) && ldw >= Np), "predict_host: variance needs the inverse factor");
   GPK_REQUIRE(h, h->batch == 1, "predict_host: not available in batched mode");
   const int64_t Mp = gpk_padded(M);
-  // pinned host block [Xq | pad][mean | var | pad]; device block [Xq | pad][K* work panel of the variance GEMM]
+  const bool small = h->small_path && gpk_small_ok(gpk_padded(N), D, P, M);
+  // pinned host block [Xq | pad][mean | var | pad]; device block [Xq | pad][work: the K* panel of the variance GEMM,
+  // or the small-batch kernels' K* and shares]
   const size_t nq = ((size_t)M * D + 15) & ~(size_t)15, nm = (size_t)M * P, nv = (size_t)M;
   const size_t nout_pad = (nm + nv + 15) & ~(size_t)15;
   const size_t host_need = (nq + nout_pad) * sizeof(double);
-  const size_t dev_need = (nq + (var_host ? (size_t)Mp * Np : 0)) * sizeof(double);
+  const size_t work_need = small ? gpk_small_work_doubles(gpk_padded(N)) : (var_host ? (size_t)Mp * Np : 0);
+  const size_t dev_need = (nq + work_need) * sizeof(double);
   if (host_need > h->serve_host_bytes || dev_need > h->serve_dev_bytes) {
     GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
     if (host_need > h->serve_host_bytes) {
@@ -177,17 +184,24 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
       h->serve_dev_bytes = want;
     }
   }
-  // The staging block is pinned, coherent host memory mapped into the device's address space: the queries go to
-  // HBM with one async copy (every workgroup re-reads them), mean / variance are written by the kernels straight
-  // into the pinned block (a few hundred bytes over PCIe): no download command, one stream synchronisation.
+  // The staging block is pinned, coherent host memory mapped into the device's address space: mean / variance are
+  // written by the kernels straight into it (a few hundred bytes over PCIe): no download command, one stream
+  // synchronisation.  Small batches (<= 32 queries): the kernels read the queries from it as well -- two launches,
+  // no copy command (gpk_small.hip).  Otherwise the queries go to HBM with one async copy (every workgroup re-reads
+  // them) ahead of the general chain.
   double* hq = (double*)h->serve_host;
   double* hout = hq + nq;                      // [mean | var]
   double* dq = (double*)h->serve_dev;
   double* dwork = dq + nq;
   memcpy(hq, Xq_host, (size_t)M * D * sizeof(double));
-  GPK_CHECK_HIP(h, hipMemcpyAsync(dq, hq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  GPK_TRY(gpk_predict_mean(h, GPK_F64, X, alpha, N, D, P, ls, sf2, y_mean, y_std, dq, M, hout));
-  if (var_host) GPK_TRY(gpk_predict_var_inv(h, GPK_F64, X, N, D, ls, sf2, W, Np, ldw, dq, M, kss, floor_, dwork, hout + nm));
+  if (small) {
+    GPK_TRY(gpk_small_predict(h, X, alpha, N, D, P, ls, sf2, y_mean, y_std, W, gpk_padded(N), ldw, kss, floor_, hq, M, dwork,
+                              hout, var_host ? hout + nm : nullptr));
+  } else {
+    GPK_CHECK_HIP(h, hipMemcpyAsync(dq, hq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    GPK_TRY(gpk_predict_mean(h, GPK_F64, X, alpha, N, D, P, ls, sf2, y_mean, y_std, dq, M, hout));
+    if (var_host) GPK_TRY(gpk_predict_var_inv(h, GPK_F64, X, N, D, ls, sf2, W, Np, ldw, dq, M, kss, floor_, dwork, hout + nm));
+  }
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   memcpy(mean_host, hout, nm * sizeof(double));
   if (var_host) memcpy(var_host, hout + nm, nv * sizeof(double));

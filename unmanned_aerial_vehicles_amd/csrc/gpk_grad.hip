@@ -11,33 +11,14 @@
 // strictly-lower elements count twice (symmetry).  Block partials are reduced in a fixed
 // order by a second kernel (deterministic).
 #include "gpk_internal.h"
+#include "gpk_math.h"
 
 namespace {
 
 constexpr int TS = 64, DMAXG = 16, GW = DMAXG + 2;   // block partial: D (<= 16) + noise + sf2
 struct LsG { double v[DMAXG]; };
 
-__device__ __forceinline__ double exp_neg64(double x) {
-  x = fmax(x, -800.0);
-  const double k = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(k, -6.93147180559945286227e-01, x);
-  r = __builtin_fma(k, -2.31904681384629955842e-17, r);
-  double p = 1.6059043836821613e-10;
-  p = __builtin_fma(p, r, 2.08767569878680990e-09);
-  p = __builtin_fma(p, r, 2.50521083854417188e-08);
-  p = __builtin_fma(p, r, 2.75573192239858907e-07);
-  p = __builtin_fma(p, r, 2.75573192239858907e-06);
-  p = __builtin_fma(p, r, 2.48015873015873016e-05);
-  p = __builtin_fma(p, r, 1.98412698412698413e-04);
-  p = __builtin_fma(p, r, 1.38888888888888889e-03);
-  p = __builtin_fma(p, r, 8.33333333333333333e-03);
-  p = __builtin_fma(p, r, 4.16666666666666667e-02);
-  p = __builtin_fma(p, r, 1.66666666666666667e-01);
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)k);
-}
+__device__ __forceinline__ double exp_neg64(double x) { return gpk_exp_neg(x); }
 
 // grid-stride over lower-triangular 64 x 64 tiles; D <= 16
 __global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict__ X, long long N, int D, LsG ls,

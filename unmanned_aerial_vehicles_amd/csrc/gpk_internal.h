@@ -22,6 +22,7 @@ struct gpk_context {
   int* d_info = nullptr;        // device int for potrf pivot failures
   double* d_small = nullptr;    // 4 KiB device doubles for reductions
   double* h_small = nullptr;    // pinned host mirror
+  unsigned* d_count = nullptr;  // two zero-initialised ticket counters (last-workgroup reductions, gpk_small.hip)
   // staging of gpk_predict_host: device block [Xq | mean | var | K* work] and its pinned host mirror [Xq | mean | var]
   void* serve_dev = nullptr;
   size_t serve_dev_bytes = 0;
@@ -30,6 +31,7 @@ struct gpk_context {
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 128;
+  int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // batched mode (gpk_batch_begin .. gpk_batch_end): `batch` same-shaped problems per call.  Pointers passed
@@ -119,6 +121,17 @@ inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int
 }
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);
 int gpk_gemm_tile(gpk_handle h, const GemmArgs& g);   // 128 or 64: the tile edge gpk_gemm will pick
+
+// ---- small-batch serving kernels (gpk_small.hip) -------------------------------------
+constexpr int GPK_SMALL_MAX_M = 32;          // queries per call
+constexpr int64_t GPK_SMALL_MAX_NP = 16384;  // padded training rows
+bool gpk_small_ok(int64_t Np, int D, int P, int64_t M);
+size_t gpk_small_work_doubles(int64_t Np);   // device work area: K* (32 x Np) + the workgroups' shares
+// mean (M x P) and, if var_out, variance (M) of M <= 32 fp64 queries; Xq / mean_out / var_out may be mapped host memory
+int gpk_small_predict(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P, const double* ls,
+                      double sf2, const double* y_mean, const double* y_std, const double* W, int64_t Np, int64_t ldw,
+                      double kss, double floor_, const double* Xq, int64_t M, double* work, double* mean_out,
+                      double* var_out);
 
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out);

@@ -135,6 +135,7 @@ class DeviceGP:
         self.sf2 = None
         self._f32 = None    # dict of fp32 copies: X, alpha [, L, winv]
         self._Winv = {}     # explicit inverse factor L^-1: {'f64': tensor} and/or {'f32': tensor}
+        self._host_args = None   # predict_host: cached argument addresses
         self._Kinv = None
 
     # ---- fit-side -------------------------------------------------------------------------
@@ -362,19 +363,24 @@ class DeviceGP:
             raise ValueError(f"queries must be (M, {self.D})")
         mean = np.empty((M, self.P))
         var = np.empty((M,)) if kss is not None else None
-        ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
-        ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
         W = self.inverse_factor(False) if kss is not None else None
         be = self.be
-        dp = _lib._dp
+        # the addresses that do not change between calls are looked up once per (factorisation, target scaling):
+        # this call runs at the control rate and every ctypes conversion costs about a microsecond
+        c = self._host_args
+        if (c is None or c[0] is not self.X or c[1] is not self.alpha or c[2] is not self.ls or c[3] is not y_mean
+                or c[4] is not y_std):
+            ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
+            ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
+            c = self._host_args = (self.X, self.alpha, self.ls, y_mean, y_std, ym, ys, self.X.data_ptr(),
+                                   self.alpha.data_ptr(), self.ls.ctypes.data, ym.ctypes.data, ys.ctypes.data)
         with be.lock:
             be.bind_stream()
-            be.check(be.lib.gpk_predict_host(be.h, _p(self.X), _p(self.alpha), self.N, self.D, self.P,
-                                             self.ls.ctypes.data_as(dp), self.sf2, ym.ctypes.data_as(dp),
-                                             ys.ctypes.data_as(dp), _p(W) if W is not None else None, self.Np, self.Np,
+            be.check(be.lib.gpk_predict_host(be.h, c[7], c[8], self.N, self.D, self.P, c[9], self.sf2, c[10], c[11],
+                                             W.data_ptr() if W is not None else None, self.Np, self.Np,
                                              float(kss) if kss is not None else 0.0, float(floor),
-                                             Xq.ctypes.data_as(dp), M, mean.ctypes.data_as(dp),
-                                             var.ctypes.data_as(dp) if var is not None else None))
+                                             Xq.ctypes.data, M, mean.ctypes.data,
+                                             var.ctypes.data if var is not None else None))
         return mean, var
 
     def inverse_factor(self, f32):
