@@ -337,6 +337,15 @@ def test_small_batch_kernels_vs_oracle():
                 assert relerr(np.reshape(mean, (M, P)), om) < 1e-10, (N, D, P, M)
                 assert relerr(np.reshape(std, (M, P)), os_) < 1e-9, (N, D, P, M)
             assert np.array_equal(gp.predict(Xq), mean)
+    # the largest training set the small-batch kernels take (Np = 16384: 512 + 1024 workgroups, 256 k-chunks) against
+    # the general kernels (a 33-row batch)
+    Xl = rng.standard_normal((16300, 6)); Yl = np.sin(Xl[:, :2] * 1.1) + 0.05 * rng.standard_normal((16300, 2))
+    gl = GaussianProcessRegressor(kernel=RBF(1.4) + WhiteKernel(0.05), alpha=1e-6, normalize_y=True, optimizer=None).fit(Xl, Yl)
+    Xq = rng.standard_normal((33, 6))
+    m32, s32 = gl.predict(Xq[:32], return_std=True)
+    m33, s33 = gl.predict(Xq, return_std=True)
+    assert relerr(m32, m33[:32]) < 1e-11 and relerr(s32, s33[:32]) < 1e-9
+    del gl
     # far-away queries: the variance is the prior's, the mean the training mean; a query on a training point: clipped at >= 0
     gp = GaussianProcessRegressor(kernel=RBF(1.0) + WhiteKernel(1e-6), alpha=0.0, normalize_y=False, optimizer=None).fit(X[:200], Y[:200])
     mean, std = gp.predict(np.vstack([X[:3], 50.0 + X[:2]]), return_std=True)

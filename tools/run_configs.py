@@ -71,7 +71,8 @@ def main():
     t_train = time.perf_counter() - t0
     t_single, _ = wall(lambda: gp.predict_residual(X10[24, :6], X10[24, 6:]), reps=20)
     t_batch, _ = wall(lambda: gp.gp_model.predict(X10, return_std=True), reps=5)
-    t_hor, _ = wall(lambda: gp.build_gp_residuals(ka["ka3_hor_X"], ka["ka3_hor_U"], 0.1), reps=20)
+    hor_X, hor_U = np.asarray(ka["ka3_hor_X"]), np.asarray(ka["ka3_hor_U"])     # (an .npz member is re-read on every access)
+    t_hor, _ = wall(lambda: gp.build_gp_residuals(hor_X, hor_U, 0.1), reps=20)
     c1 = {"train_gp_s": t_train, "lml": gp.gp_model.log_marginal_likelihood_value_,
           "lml_reference": float(ka["ka3_lml"]), "kernel": str(gp.gp_model.kernel_),
           "predict_residual_single_ms": t_single * 1e3, "predict_1000_rows_mean_std_ms": t_batch * 1e3,
