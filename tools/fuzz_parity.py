@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from oracle import gp_oracle as O  # noqa: E402
-from unmanned_aerial_vehicles_amd import RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel  # noqa: E402
+from unmanned_aerial_vehicles_amd import GaussianProcess, RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel  # noqa: E402
 
 cases = int(os.environ.get("FUZZ_CASES", "150"))
 seed = int(os.environ.get("FUZZ_SEED", "0"))
@@ -77,5 +77,33 @@ for c in range(cases):
     if not ok:
         bad += 1
     print(("ok   " if ok else "FAIL ") + tag + f"  mean {e_mean:.1e} std {e_std:.1e} lml {e_lml:.1e} grad {e_grad:.1e}", flush=True)
-print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
+# ---- the ROS-package GP (gaussian_process.py:63-265): no target scaling, variance floored at 1e-10, its own LML
+pk_cases = int(os.environ.get("FUZZ_PACKAGE_CASES", str(max(cases // 3, 1))))
+for c in range(pk_cases):
+    N, M = pick(min(max_n, 2000)), pick(600)
+    D, P = int(rng.integers(1, 17)), int(rng.integers(1, 13))
+    ls = float(np.exp(rng.uniform(np.log(0.6), np.log(3.0))) * np.sqrt(D) / 2)
+    sf2, noise = float(np.exp(rng.uniform(-1, 1))), float(np.exp(rng.uniform(np.log(1e-3), np.log(0.3))))
+    X = rng.standard_normal((N, D)); Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+    Xq = rng.standard_normal((M, D))
+    tag = f"package case {c}: N={N} M={M} D={D} P={P} ls={ls:.3g} sf2={sf2:.3g} noise={noise:.3g}"
+    gp = GaussianProcess(input_dim=D, output_dim=P)
+    gp.max_data_points = 10 ** 9
+    gp.kernel.length_scale, gp.kernel.signal_variance, gp.noise_variance = ls, sf2, noise
+    gp.add_training_data(X, Y)
+    gp.fit()
+    if N < 2:                         # the reference refuses to fit and predicts the prior
+        m, v = gp.predict(Xq)
+        ok = np.all(m == 0) and np.allclose(v, sf2)
+        e_mean = e_var = e_lml = 0.0
+    else:
+        m, v = gp.predict(Xq)
+        o = O.PackageGPOracle(ls, sf2, noise).fit(X, Y)
+        om, ov = o.predict(Xq)
+        e_mean, e_var = rel(m, om), rel(v, ov)
+        e_lml = abs(gp.log_marginal_likelihood() - o.log_marginal_likelihood()) / abs(o.log_marginal_likelihood())
+        ok = e_mean < 1e-8 and e_var < 1e-7 and e_lml < 1e-9 and v.shape == (M, P)
+    bad += not ok
+    print(("ok   " if ok else "FAIL ") + tag + f"  mean {e_mean:.1e} var {e_var:.1e} lml {e_lml:.1e}", flush=True)
+print(f"{cases} + {pk_cases} cases, {bad} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

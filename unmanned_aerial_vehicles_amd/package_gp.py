@@ -94,8 +94,8 @@ class GaussianProcess:
             return
         try:
             dev = self._factor(self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance)
-            with self._swap:
-                self._model = (dev, float(self.kernel.signal_variance))
+            with self._swap:      # (the zero / one target scaling is kept with the model: predict_host caches by identity)
+                self._model = (dev, float(self.kernel.signal_variance), np.zeros(dev.P), np.ones(dev.P))
             self.alpha = dev.alpha_host()
             self.L = _LazyFactor(dev)
         except NotPositiveDefinite as e:
@@ -120,12 +120,12 @@ class GaussianProcess:
         if model is None:           # failed fit: alpha = 0, L missing -> the reference's except branch
             return prior
         try:
-            dev, sf2 = model
+            dev, sf2, zeros, ones = model
             if self.predict_dtype != "float32" and dev.host_path_ok(len(X_test), True):
                 # small batches: one C call and one synchronisation (gpk_predict_host)
-                mean, var = dev.predict_host(X_test, np.zeros(dev.P), np.ones(dev.P), sf2, 1e-10)
+                mean, var = dev.predict_host(X_test, zeros, ones, sf2, 1e-10)
                 return mean, np.tile(var.reshape(-1, 1), (1, self.output_dim))
-            mean = dev.predict_mean_dev(X_test, np.zeros(dev.P), np.ones(dev.P), self.predict_dtype)
+            mean = dev.predict_mean_dev(X_test, zeros, ones, self.predict_dtype)
             var = dev.predict_var_dev(X_test, sf2, 1e-10, self.predict_dtype)
             mean = mean.double().cpu().numpy()
             var = np.tile(var.cpu().numpy().reshape(-1, 1), (1, self.output_dim))
