@@ -140,12 +140,25 @@ int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, 
  * mean_host: M x P (un-normalised with y_mean / y_std); var_host: M (normalised-target units: the caller
  * scales by y_std^2), clipped below at floor_.  1 <= M <= GPK_HOST_MAX_M.
  * Replaces: the per-call path of src/px4/simple_gp.py:187-201 (predict_residual) and the 25-call loop of
- * src/px4/mpc.py:1490-1506; sklearn/_gpr.py:441-494.                                                     */
+ * src/px4/mpc.py:1490-1506; sklearn/_gpr.py:441-494.
+ * Up to 32 queries (D, P <= 16, N <= 16384) take two dedicated launches (K* + mean shares; 16 rows of W per
+ * workgroup on the fp64 MFMA, last-workgroup reductions) instead of the general chain's seven.           */
 #define GPK_HOST_MAX_M 4096
 int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P,
                      const double* ls, double sf2, const double* y_mean, const double* y_std,
                      const double* W, int64_t Np, int64_t ldw, double kss, double floor_,
                      const double* Xq_host, int64_t M, double* mean_host, double* var_host);
+
+/* The same one-call serving for B <= 8 single-output models that share the query batch - the per-axis GPs of
+ * gp_trainer.py / pretrained_gp.py - in ONE call and two launches (model = second grid dimension).
+ * X, alpha, W: arrays of B device pointers (N x D, N x 1, Np x ldw); ls: B x D (host); sf2, y_mean, y_std, kss:
+ * B (host).  1 <= M <= 32, D <= 16, N <= 16384.  mean_host: B x M (un-normalised); var_host: B x M in
+ * normalised-target units, or NULL (then W and kss may be NULL).
+ * Replaces: the loop over six scalar GPs of src/px4/pretrained_gp.py:52-98.                                 */
+int gpk_predict_host_multi(gpk_handle h, int B, const double* const* X, const double* const* alpha, int64_t N, int D,
+                           const double* ls, const double* sf2, const double* y_mean, const double* y_std,
+                           const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
+                           const double* Xq_host, int64_t M, double* mean_host, double* var_host);
 
 /* K4 on the matrix cores, fp32 only: the same posterior mean as gpk_predict_mean(GPK_F32, ...), with the
  * pairwise squared distances of 32 x 32 (query, training point) blocks formed by v_mfma_f32_32x32x2_f32

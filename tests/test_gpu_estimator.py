@@ -460,6 +460,20 @@ def test_batched_per_axis_ard_gps(csv_data, ka):
     bg2._fused = None
     ref1 = bg2.models[1].predict(Xq)
     assert relerr(bg2.predict(Xq)[:, 1], ref1) < 1e-12
+    # control-loop batches (<= 32 rows): all models in one C call and two launches (gpk_predict_host_multi)
+    for M in (1, 16, 25, 32):
+        mean_m, std_m = bg2.predict(Xq[:M], return_std=True)
+        assert bg2._serve is not None and bg2._serve["ok"] and mean_m.shape == (M, 3) and std_m.shape == (M, 3)
+        ref = [m.predict(Xq[:M], return_std=True) for m in bg2.models]
+        assert relerr(mean_m, np.stack([r[0] for r in ref], axis=1)) < 1e-11
+        assert relerr(std_m, np.stack([r[1] for r in ref], axis=1)) < 1e-9
+        assert np.array_equal(bg2.predict(Xq[:M]), mean_m)
+    bg2.models[2].kernel_.theta = bg2.models[2].kernel_.theta - 0.3      # a refit model is picked up
+    bg2.models[2]._refactor()
+    bg2._fused = None
+    m2, s2 = bg2.predict(Xq[:5], return_std=True)
+    r2 = bg2.models[2].predict(Xq[:5], return_std=True)
+    assert relerr(m2[:, 2], r2[0]) < 1e-11 and relerr(s2[:, 2], r2[1]) < 1e-9
 
 
 def test_batched_large_fp32_batches_use_matrix_core_kernel():

@@ -50,3 +50,25 @@ print("be.bind_stream()                %.1f us" % med(lambda: be.bind_stream()))
 print("kernel_.components()            %.1f us" % med(lambda: gp.kernel_.components()))
 print("_p(tensor)                      %.1f us" % med(lambda: _p(dev.X)))
 print("ndarray.ctypes.data_as          %.1f us" % med(lambda: q1.ctypes.data_as(_lib._dp)))
+
+# ---- six per-axis ARD GPs (gp_trainer.py / pretrained_gp.py:52-98): one fused call against the per-model loop
+from unmanned_aerial_vehicles_amd import BatchedARDGP  # noqa: E402
+Nt = 800
+Y6 = np.sin(X[:Nt] @ rng.standard_normal((D, 6))) + 0.05 * rng.standard_normal((Nt, 6))
+bg = BatchedARDGP(length_scale=np.full(D, 2.0), noise_level=0.05, alpha=1e-6, normalize_y=False, optimizer=None).fit(X[:Nt], Y6)
+for M in (1, 25):
+    q = X[:M] + 0.01
+    print(f"6 per-axis GPs, M={M}")
+    print("  fused call (mean + std)       %.1f us" % med(lambda: bg.predict(q, return_std=True)))
+    print("  fused call (mean)             %.1f us" % med(lambda: bg.predict(q)))
+    print("  per-model loop (mean + std)   %.1f us" % med(lambda: [m.predict(q, return_std=True) for m in bg.models], 500))
+try:
+    from sklearn.gaussian_process import GaussianProcessRegressor as SkGPR
+    from sklearn.gaussian_process.kernels import RBF as SkRBF, ConstantKernel as SkC, WhiteKernel as SkW
+    sks = [SkGPR(kernel=SkC(1.0, "fixed") * SkRBF(np.full(D, 2.0)) + SkW(0.05), alpha=1e-6, optimizer=None).fit(X[:Nt], Y6[:, i])
+           for i in range(6)]
+    for M in (1, 25):
+        q = X[:M] + 0.01
+        print(f"  scikit-learn loop over 6 GPs, M={M} (mean + std)  %.1f us" % med(lambda: [g.predict(q, return_std=True) for g in sks], 200))
+except ImportError:
+    pass

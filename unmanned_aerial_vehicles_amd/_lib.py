@@ -48,6 +48,8 @@ SIGNATURES = {
     # (host pointers as void*: the serving path passes cached integer addresses)
     "gpk_predict_host": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _dbl, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _vp,
                                 _i64, _vp, _vp]),
+    "gpk_predict_host_multi": (_int, [_vp, _int, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _dbl, _vp,
+                                      _i64, _vp, _vp]),
     "gpk_predict_mean_mfma": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_mean_multi": (_int, [_vp, _int, _vp, _vp, _i64, _int, _int, _dp, _dp, _dp, _dp, _vp, _i64, _vp]),
     "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,

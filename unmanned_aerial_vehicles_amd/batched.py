@@ -34,10 +34,12 @@ class BatchedARDGP:
         self._workers = []
         self._fused = None
         self._fs = None
+        self._serve = None
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_workers"], st["_fused"], st["_fs"] = [], None, None   # handles, streams, device tensors: rebuilt lazily
+        st["_serve"] = None
         return st
 
     # ------------------------------------------------------------------ workers
@@ -283,8 +285,84 @@ class BatchedARDGP:
                 f["ys"].ctypes.data_as(dp), C.c_void_p(q.data_ptr()), M, C.c_void_p(out.data_ptr())))
         return out
 
+    # ------------------------------------------------------------------ control-loop batches
+    SERVE_MAX_M = 32
+
+    def _serve_state(self, want_std):
+        """Argument block of `gpk_predict_host_multi` (one call, two launches for all models), or None when the
+        models do not qualify: fp64 serving, single-output models on one device with the same training-set size,
+        D <= 16, N <= 16384, at most 8 of them.  Rebuilt when a model has been refitted."""
+        import torch
+        ms = self.models
+        if self.predict_dtype == "float32" or not (1 <= len(ms) <= 8):
+            return None
+        for m in ms:
+            m._ensure_device()
+        devs = [m._dev for m in ms]
+        key = tuple((id(d), id(d.ls), d.factored) for d in devs)
+        sv = getattr(self, "_serve", None)
+        if sv is None or sv["key"] != key:
+            d0 = devs[0]
+            ok = all(d.factored and d.P == 1 and d.N == d0.N and d.D == d0.D and d.be.device == d0.be.device for d in devs)
+            if not ok or d0.D > 16 or d0.Np > 16384:
+                self._serve = {"key": key, "ok": False}
+                return None
+            comps = [m.kernel_.components() for m in ms]
+            B = len(ms)
+            vp = C.c_void_p * B
+            sv = self._serve = {
+                "key": key, "ok": True, "B": B, "dev0": d0, "keep": devs,
+                "X": vp(*[d.X.data_ptr() for d in devs]), "alpha": vp(*[d.alpha.data_ptr() for d in devs]),
+                "ls": np.ascontiguousarray(np.stack([d.ls for d in devs])),
+                "sf2": np.ascontiguousarray([d.sf2 for d in devs], dtype=np.float64),
+                "ym": np.ascontiguousarray([m._y_train_mean[0] for m in ms], dtype=np.float64),
+                "ys": np.ascontiguousarray([m._y_train_std[0] for m in ms], dtype=np.float64),
+                "kss": np.ascontiguousarray([c.sf2 + (c.noise or 0.0) for c in comps], dtype=np.float64),
+                "W": None,
+            }
+            with torch.cuda.device(d0.be.device):
+                torch.cuda.synchronize()          # the models may have been fitted on their own streams
+        if not sv["ok"]:
+            return None
+        if want_std and sv["W"] is None:
+            if not all(d.host_path_ok(1, True) for d in sv["keep"]):
+                return None
+            Ws = [d.inverse_factor(False) for d in sv["keep"]]
+            with torch.cuda.device(sv["dev0"].be.device):
+                torch.cuda.synchronize()
+            sv["Wt"] = Ws
+            sv["W"] = (C.c_void_p * sv["B"])(*[w.data_ptr() for w in Ws])
+        return sv
+
+    def predict_host(self, Xq, return_std=False):
+        """<= 32 rows, all models, one C call: (mean (M, B), std (M, B) or None); None if the models do not qualify."""
+        sv = self._serve_state(return_std)
+        if sv is None:
+            return None
+        Xq = np.ascontiguousarray(Xq, dtype=np.float64)
+        M, B, d0 = Xq.shape[0], sv["B"], sv["dev0"]
+        if Xq.ndim != 2 or Xq.shape[1] != d0.D:
+            raise ValueError(f"queries must be (M, {d0.D})")
+        mean = np.empty((B, M))
+        var = np.empty((B, M)) if return_std else None
+        be = d0.be
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_predict_host_multi(
+                be.h, B, sv["X"], sv["alpha"], d0.N, d0.D, sv["ls"].ctypes.data, sv["sf2"].ctypes.data,
+                sv["ym"].ctypes.data, sv["ys"].ctypes.data, sv["W"] if return_std else None, d0.Np, d0.Np,
+                sv["kss"].ctypes.data, 0.0, Xq.ctypes.data, M, mean.ctypes.data,
+                var.ctypes.data if return_std else None))
+        if not return_std:
+            return mean.T, None
+        return mean.T, (np.sqrt(var) * sv["ys"][:, None]).T
+
     def predict(self, Xq, return_std=False):
         Xq = np.atleast_2d(np.asarray(Xq, dtype=np.float64))
+        if 1 <= Xq.shape[0] <= self.SERVE_MAX_M:
+            out = self.predict_host(Xq, return_std)
+            if out is not None:
+                return out if return_std else out[0]
         mean = self.predict_mean_dev(Xq).double().cpu().numpy()
         if not return_std:
             return mean

@@ -18,8 +18,8 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&h->d_info, GPK_MAX_BATCH * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->d_small, 4096) != hipSuccess ||
-      hipMalloc((void**)&h->d_count, 2 * sizeof(unsigned)) != hipSuccess ||
-      hipMemset(h->d_count, 0, 2 * sizeof(unsigned)) != hipSuccess ||
+      hipMalloc((void**)&h->d_count, 2 * GPK_SMALL_MAX_MODELS * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(h->d_count, 0, 2 * GPK_SMALL_MAX_MODELS * sizeof(unsigned)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_small, 4096, hipHostMallocDefault) != hipSuccess) {
     delete h;
     return GPK_HIP_ERROR;
@@ -149,6 +149,27 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
 }
 
 // ---- one-call serving for the control loop: host queries in, host mean / variance out ------------------
+// Grow the serving staging blocks (pinned, device-mapped host block; device work block) to at least these sizes.
+static int serve_reserve(gpk_handle h, size_t host_need, size_t dev_need) {
+  if (host_need <= h->serve_host_bytes && dev_need <= h->serve_dev_bytes) return GPK_OK;
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  if (host_need > h->serve_host_bytes) {
+    if (h->serve_host) GPK_CHECK_HIP(h, hipHostFree(h->serve_host));
+    h->serve_host = nullptr; h->serve_host_bytes = 0;
+    const size_t want = (host_need + 65535) & ~(size_t)65535;
+    GPK_CHECK_HIP(h, hipHostMalloc(&h->serve_host, want, hipHostMallocMapped | hipHostMallocCoherent));
+    h->serve_host_bytes = want;
+  }
+  if (dev_need > h->serve_dev_bytes) {
+    if (h->serve_dev) GPK_CHECK_HIP(h, hipFree(h->serve_dev));
+    h->serve_dev = nullptr; h->serve_dev_bytes = 0;
+    const size_t want = (dev_need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    GPK_CHECK_HIP(h, hipMalloc(&h->serve_dev, want));
+    h->serve_dev_bytes = want;
+  }
+  return GPK_OK;
+}
+
 extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P,
                                 const double* ls, double sf2, const double* y_mean, const double* y_std,
                                 const double* W, int64_t Np, int64_t ldw, double kss, double floor_,
@@ -165,25 +186,9 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
   const size_t nq = ((size_t)M * D + 15) & ~(size_t)15, nm = (size_t)M * P, nv = (size_t)M;
   const size_t nout_pad = (nm + nv + 15) & ~(size_t)15;
   const size_t host_need = (nq + nout_pad) * sizeof(double);
-  const size_t work_need = small ? gpk_small_work_doubles(gpk_padded(N)) : (var_host ? (size_t)Mp * Np : 0);
+  const size_t work_need = small ? gpk_small_work_doubles(gpk_padded(N), 1) : (var_host ? (size_t)Mp * Np : 0);
   const size_t dev_need = (nq + work_need) * sizeof(double);
-  if (host_need > h->serve_host_bytes || dev_need > h->serve_dev_bytes) {
-    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-    if (host_need > h->serve_host_bytes) {
-      if (h->serve_host) GPK_CHECK_HIP(h, hipHostFree(h->serve_host));
-      h->serve_host = nullptr; h->serve_host_bytes = 0;
-      const size_t want = (host_need + 65535) & ~(size_t)65535;
-      GPK_CHECK_HIP(h, hipHostMalloc(&h->serve_host, want, hipHostMallocMapped | hipHostMallocCoherent));
-      h->serve_host_bytes = want;
-    }
-    if (dev_need > h->serve_dev_bytes) {
-      if (h->serve_dev) GPK_CHECK_HIP(h, hipFree(h->serve_dev));
-      h->serve_dev = nullptr; h->serve_dev_bytes = 0;
-      const size_t want = (dev_need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-      GPK_CHECK_HIP(h, hipMalloc(&h->serve_dev, want));
-      h->serve_dev_bytes = want;
-    }
-  }
+  GPK_TRY(serve_reserve(h, host_need, dev_need));
   // The staging block is pinned, coherent host memory mapped into the device's address space: mean / variance are
   // written by the kernels straight into it (a few hundred bytes over PCIe): no download command, one stream
   // synchronisation.  Small batches (<= 32 queries): the kernels read the queries from it as well -- two launches,
@@ -195,13 +200,38 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
   double* dwork = dq + nq;
   memcpy(hq, Xq_host, (size_t)M * D * sizeof(double));
   if (small) {
-    GPK_TRY(gpk_small_predict(h, X, alpha, N, D, P, ls, sf2, y_mean, y_std, W, gpk_padded(N), ldw, kss, floor_, hq, M, dwork,
-                              hout, var_host ? hout + nm : nullptr));
+    GPK_TRY(gpk_small_predict(h, 1, &X, &alpha, N, D, P, ls, &sf2, y_mean, y_std, &W, gpk_padded(N), ldw, &kss, floor_, hq, M,
+                              dwork, hout, var_host ? hout + nm : nullptr));
   } else {
     GPK_CHECK_HIP(h, hipMemcpyAsync(dq, hq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
     GPK_TRY(gpk_predict_mean(h, GPK_F64, X, alpha, N, D, P, ls, sf2, y_mean, y_std, dq, M, hout));
     if (var_host) GPK_TRY(gpk_predict_var_inv(h, GPK_F64, X, N, D, ls, sf2, W, Np, ldw, dq, M, kss, floor_, dwork, hout + nm));
   }
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  memcpy(mean_host, hout, nm * sizeof(double));
+  if (var_host) memcpy(var_host, hout + nm, nv * sizeof(double));
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_host_multi(gpk_handle h, int B, const double* const* X, const double* const* alpha, int64_t N,
+                                      int D, const double* ls, const double* sf2, const double* y_mean, const double* y_std,
+                                      const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
+                                      const double* Xq_host, int64_t M, double* mean_host, double* var_host) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && alpha && ls && sf2 && y_mean && y_std && Xq_host && mean_host, "predict_host_multi: null pointer");
+  GPK_REQUIRE(h, B >= 1 && B <= GPK_SMALL_MAX_MODELS, "predict_host_multi: 1..8 models");
+  GPK_REQUIRE(h, N >= 1 && gpk_small_ok(gpk_padded(N), D, 1, M), "predict_host_multi: needs M <= 32, D <= 16, N <= 16384");
+  GPK_REQUIRE(h, !var_host || (W && kss && Np == gpk_padded(N) && ldw >= Np), "predict_host_multi: variance needs the inverse factors");
+  GPK_REQUIRE(h, h->batch == 1, "predict_host_multi: not available in batched mode");
+  const size_t nq = ((size_t)M * D + 15) & ~(size_t)15, nm = (size_t)B * M, nv = (size_t)B * M;
+  const size_t nout_pad = (nm + nv + 15) & ~(size_t)15;
+  GPK_TRY(serve_reserve(h, (nq + nout_pad) * sizeof(double), (nq + gpk_small_work_doubles(gpk_padded(N), B)) * sizeof(double)));
+  double* hq = (double*)h->serve_host;
+  double* hout = hq + nq;                      // [mean (B x M) | var (B x M)]
+  double* dwork = (double*)h->serve_dev + nq;
+  memcpy(hq, Xq_host, (size_t)M * D * sizeof(double));
+  GPK_TRY(gpk_small_predict(h, B, X, alpha, N, D, 1, ls, sf2, y_mean, y_std, W, gpk_padded(N), ldw, kss, floor_, hq, M, dwork,
+                            hout, var_host ? hout + nm : nullptr));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   memcpy(mean_host, hout, nm * sizeof(double));
   if (var_host) memcpy(var_host, hout + nm, nv * sizeof(double));

@@ -22,7 +22,7 @@ struct gpk_context {
   int* d_info = nullptr;        // device int for potrf pivot failures
   double* d_small = nullptr;    // 4 KiB device doubles for reductions
   double* h_small = nullptr;    // pinned host mirror
-  unsigned* d_count = nullptr;  // two zero-initialised ticket counters (last-workgroup reductions, gpk_small.hip)
+  unsigned* d_count = nullptr;  // 2 x 8 zero-initialised ticket counters (last-workgroup reductions, gpk_small.hip)
   // staging of gpk_predict_host: device block [Xq | mean | var | K* work] and its pinned host mirror [Xq | mean | var]
   void* serve_dev = nullptr;
   size_t serve_dev_bytes = 0;
@@ -125,13 +125,16 @@ int gpk_gemm_tile(gpk_handle h, const GemmArgs& g);   // 128 or 64: the tile edg
 // ---- small-batch serving kernels (gpk_small.hip) -------------------------------------
 constexpr int GPK_SMALL_MAX_M = 32;          // queries per call
 constexpr int64_t GPK_SMALL_MAX_NP = 16384;  // padded training rows
+constexpr int GPK_SMALL_MAX_MODELS = 8;      // single-output models served by one call
 bool gpk_small_ok(int64_t Np, int D, int P, int64_t M);
-size_t gpk_small_work_doubles(int64_t Np);   // device work area: K* (32 x Np) + the workgroups' shares
-// mean (M x P) and, if var_out, variance (M) of M <= 32 fp64 queries; Xq / mean_out / var_out may be mapped host memory
-int gpk_small_predict(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P, const double* ls,
-                      double sf2, const double* y_mean, const double* y_std, const double* W, int64_t Np, int64_t ldw,
-                      double kss, double floor_, const double* Xq, int64_t M, double* work, double* mean_out,
-                      double* var_out);
+size_t gpk_small_work_doubles(int64_t Np, int B);   // device work area: per model K* (32 x Np) + the workgroups' shares
+// B models x P outputs each (B > 1: P == 1): mean (B, M, P) and, if var_out, variance (B, M) of M <= 32 fp64 queries
+// shared by the models; Xq / mean_out / var_out may be mapped host memory.  X / alpha / W: B device pointers;
+// ls: B x D; sf2, kss: B; y_mean, y_std: B * P.
+int gpk_small_predict(gpk_handle h, int B, const double* const* X, const double* const* alpha, int64_t N, int D, int P,
+                      const double* ls, const double* sf2, const double* y_mean, const double* y_std,
+                      const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
+                      const double* Xq, int64_t M, double* work, double* mean_out, double* var_out);
 
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out);

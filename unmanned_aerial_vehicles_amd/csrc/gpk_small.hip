@@ -21,6 +21,16 @@ namespace {
 
 constexpr int SQ = GPK_SMALL_MAX_M, SJ = 32, SD = 16, SP = 16, SR = 16;
 struct Arr16 { double v[16]; };
+// Per-model parameters (model = blockIdx.y).  One model with P <= 16 outputs, or B <= 8 single-output models that
+// share the query batch (the per-axis GPs of gp_trainer.py): output o = model * P + p indexes ymean / ystd.
+struct SmallK {
+  const double* X[GPK_SMALL_MAX_MODELS];
+  const double* alpha[GPK_SMALL_MAX_MODELS];
+  const double* W[GPK_SMALL_MAX_MODELS];
+  double ls[GPK_SMALL_MAX_MODELS][16];
+  double sf2[GPK_SMALL_MAX_MODELS], kss[GPK_SMALL_MAX_MODELS];
+  double ymean[16], ystd[16];
+};
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2v __attribute__((ext_vector_type(2)));
 
@@ -63,8 +73,8 @@ __device__ __forceinline__ double sum_shares(const double* p, unsigned first, un
 // The fixed-order sum of the mean shares, by whichever workgroup finishes last.  `lds`: 4 * SQ * SP doubles.  The
 // grouping of the sum depends on M * P only (256 threads take part whatever the workgroup size), so a mean-only
 // call and a mean + variance call return the same bits.
-__device__ __forceinline__ void finish_means(const double* pmean, unsigned shares, int M, int P, const Arr16& ymean,
-                                             const Arr16& ystd, double* mean_out, int tid, double* lds) {
+__device__ __forceinline__ void finish_means(const double* pmean, unsigned shares, int M, int P, const double* ymean,
+                                             const double* ystd, double* mean_out, int tid, double* lds) {
   constexpr int NT = 256;
   const int MP = M * P;
   const int nparts = 4 * MP <= NT ? 4 : (2 * MP <= NT ? 2 : 1);
@@ -77,7 +87,7 @@ __device__ __forceinline__ void finish_means(const double* pmean, unsigned share
       double s = lds[t];
       for (int k = 1; k < nparts; ++k) s += lds[k * (SQ * SP) + t];
       const int p = t % P;
-      mean_out[t] = ymean.v[p] + ystd.v[p] * s;
+      mean_out[t] = ymean[p] + ystd[p] * s;
     }
     if (base + chunk < MP) __syncthreads();      // another pass reuses the scratch
   }
@@ -86,13 +96,21 @@ __device__ __forceinline__ void finish_means(const double* pmean, unsigned share
 // FINISH: this launch is the only one (mean-only call) and elects the workgroup that writes the means; otherwise
 // small_var_kernel's last workgroup does it.
 template <bool FINISH>
-__global__ __launch_bounds__(256) void small_cross_mean_kernel(
-    const double* __restrict__ X, const double* __restrict__ alpha, long long N, long long Np, int D, int P,
-    Arr16 ls, double sf2, Arr16 ymean, Arr16 ystd, const double* __restrict__ Xq, int M, double* __restrict__ Ks,
-    double* pmean, unsigned* counter, double* mean_out) {
+__global__ __launch_bounds__(256) void small_cross_mean_kernel(SmallK k, long long N, long long Np, int D, int P,
+                                                               const double* __restrict__ Xq, int M, double* Ks,
+                                                               double* pmean, unsigned* counter, double* mean_out) {
   __shared__ double q[SQ][SD + 1];
   __shared__ double ks[SQ][SJ + 1];
   __shared__ double al[SJ][SP + 1];
+  const int b = blockIdx.y;
+  const double* __restrict__ X = k.X[b];
+  const double* __restrict__ alpha = k.alpha[b];
+  const double* ls = k.ls[b];
+  const double sf2 = k.sf2[b];
+  if (Ks) Ks += (long long)b * SQ * Np;
+  pmean += (long long)b * gridDim.x * (SQ * SP);
+  mean_out += (long long)b * M * P;
+  counter += b;
   const int tid = threadIdx.x, jl = tid & 31, mg = tid >> 5;
   const long long j0 = (long long)blockIdx.x * SJ, j = j0 + jl;
   const bool valid = j < N;
@@ -108,12 +126,12 @@ __global__ __launch_bounds__(256) void small_cross_mean_kernel(
 #pragma unroll
   for (int d = 0; d < SD; ++d) xr[d] = (d < D && valid) ? X[j * D + d] : 0.0;
 #pragma unroll
-  for (int d = 0; d < SD; ++d) xr[d] = xr[d] / ls.v[d];
+  for (int d = 0; d < SD; ++d) xr[d] = xr[d] / ls[d];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int e = tid + 256 * u;
     if (e < SJ * P) al[e / P][e % P] = av[u];
-    if (e < M * D) q[e / D][e % D] = qv[u] / ls.v[e % D];
+    if (e < M * D) q[e / D][e % D] = qv[u] / ls[e % D];
   }
   __syncthreads();
 #pragma unroll
@@ -143,7 +161,7 @@ __global__ __launch_bounds__(256) void small_cross_mean_kernel(
   if constexpr (FINISH) {
     if (last_workgroup(counter, tid)) {
       __shared__ double fin[4 * SQ * SP];
-      finish_means(pmean, gridDim.x, M, P, ymean, ystd, mean_out, tid, fin);
+      finish_means(pmean, gridDim.x, M, P, k.ymean + b * P, k.ystd + b * P, mean_out, tid, fin);
     }
   }
 }
@@ -181,13 +199,21 @@ __device__ __forceinline__ void vmul(const VFrag<NMB>& f, long long kc, int kq, 
 }
 
 template <int NMB>
-__global__ __launch_bounds__(64 * VW) void small_var_kernel(const double* __restrict__ W, long long ldw, long long Np,
-                                                            const double* __restrict__ Ks, int M, int P, double kss,
-                                                            double floor_, Arr16 ymean, Arr16 ystd, const double* pmean,
+__global__ __launch_bounds__(64 * VW) void small_var_kernel(SmallK k, long long ldw, long long Np, const double* Ks,
+                                                            int M, int P, double floor_, const double* pmean,
                                                             unsigned mean_shares, double* pvar, unsigned* counter,
                                                             double* mean_out, double* var_out) {
   __shared__ double red[VW][NMB][16][17];
   __shared__ double sq[NMB][16][17];
+  const int b = blockIdx.y;
+  const double* __restrict__ W = k.W[b];
+  const double kss = k.kss[b];
+  Ks += (long long)b * SQ * Np;
+  pmean += (long long)b * mean_shares * (SQ * SP);
+  pvar += (long long)b * gridDim.x * SQ;
+  mean_out += (long long)b * M * P;
+  var_out += (long long)b * M;
+  counter += b;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
   const long long r0 = (long long)blockIdx.x * SR, row = r0 + i;
   const long long kend = min(Np, (r0 + SR + 63) / 64 * 64);   // the rows' diagonal, rounded up to the chunk
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(64 * VW) void small_var_kernel(const double* __rest
   // The mean shares are complete since the previous launch: the workgroup with the shortest rows adds them up while
   // the others are still multiplying, off the critical path (scratch: the reduction buffer, free by now).
   static_assert(VW * 16 * 17 >= 4 * SQ * SP, "the reduction buffer doubles as the mean scratch");
-  if (blockIdx.x == 0) finish_means(pmean, mean_shares, M, P, ymean, ystd, mean_out, tid, &red[0][0][0][0]);
+  if (blockIdx.x == 0) finish_means(pmean, mean_shares, M, P, k.ymean + b * P, k.ystd + b * P, mean_out, tid, &red[0][0][0][0]);
   if (last_workgroup(counter, tid)) {
     __shared__ double part[2 * VW][SQ];
     const int m = tid & 31, pt = tid >> 5;
@@ -251,42 +277,51 @@ __global__ __launch_bounds__(64 * VW) void small_var_kernel(const double* __rest
 
 }  // namespace
 
-size_t gpk_small_work_doubles(int64_t Np) { return (size_t)Np * (SQ + SQ * SP / SJ + SQ / SR); }
+size_t gpk_small_work_doubles(int64_t Np, int B) { return (size_t)B * Np * (SQ + SQ * SP / SJ + SQ / SR); }
 
 bool gpk_small_ok(int64_t Np, int D, int P, int64_t M) {
   return M >= 1 && M <= SQ && D >= 1 && D <= SD && P >= 1 && P <= SP && Np <= GPK_SMALL_MAX_NP;
 }
 
-int gpk_small_predict(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P, const double* ls,
-                      double sf2, const double* y_mean, const double* y_std, const double* W, int64_t Np, int64_t ldw,
-                      double kss, double floor_, const double* Xq, int64_t M, double* work, double* mean_out,
-                      double* var_out) {
+// B models (blockIdx.y) x P outputs each (B > 1 requires P == 1).  X / alpha / W: B device pointers; ls: B x D;
+// sf2, kss: B; y_mean, y_std: B * P.  mean_out: (B, M, P), var_out: (B, M) or null.
+int gpk_small_predict(gpk_handle h, int B, const double* const* X, const double* const* alpha, int64_t N, int D, int P,
+                      const double* ls, const double* sf2, const double* y_mean, const double* y_std,
+                      const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
+                      const double* Xq, int64_t M, double* work, double* mean_out, double* var_out) {
+  GPK_REQUIRE(h, B >= 1 && B <= GPK_SMALL_MAX_MODELS && (B == 1 || P == 1), "small predict: 1 model, or up to 8 single-output models");
   GPK_REQUIRE(h, gpk_small_ok(Np, D, P, M) && Np == gpk_padded(N), "small predict: shape outside the small-batch path");
   GPK_REQUIRE(h, !var_out || (W && ldw >= Np && ldw % 2 == 0), "small predict: variance needs the inverse factor");
-  Arr16 l{}, ym{}, ys{};
-  for (int d = 0; d < 16; ++d) l.v[d] = 1.0;
-  for (int d = 0; d < D; ++d) {
-    GPK_REQUIRE(h, ls[d] > 0.0, "length-scales must be positive");
-    l.v[d] = ls[d];
+  SmallK k{};
+  for (int b = 0; b < B; ++b) {
+    GPK_REQUIRE(h, X[b] && alpha[b] && (!var_out || W[b]), "small predict: null model pointer");
+    k.X[b] = X[b]; k.alpha[b] = alpha[b]; k.W[b] = var_out ? W[b] : nullptr;
+    for (int d = 0; d < 16; ++d) k.ls[b][d] = 1.0;
+    for (int d = 0; d < D; ++d) {
+      GPK_REQUIRE(h, ls[b * D + d] > 0.0, "length-scales must be positive");
+      k.ls[b][d] = ls[b * D + d];
+    }
+    k.sf2[b] = sf2[b];
+    k.kss[b] = var_out ? kss[b] : 0.0;
   }
-  for (int p = 0; p < P; ++p) { ym.v[p] = y_mean[p]; ys.v[p] = y_std[p]; }
+  for (int o = 0; o < B * P; ++o) { k.ymean[o] = y_mean[o]; k.ystd[o] = y_std[o]; }
   const unsigned ga = (unsigned)(Np / SJ), gb = (unsigned)(Np / SR);
-  double* Ks = work;                                  // SQ x Np
-  double* pmean = Ks + (size_t)SQ * Np;               // ga x (SQ * SP)
-  double* pvar = pmean + (size_t)ga * (SQ * SP);      // gb x SQ
+  double* Ks = work;                                       // B x SQ x Np
+  double* pmean = Ks + (size_t)B * SQ * Np;                // B x ga x (SQ * SP)
+  double* pvar = pmean + (size_t)B * ga * (SQ * SP);       // B x gb x SQ
   if (var_out) {
-    hipLaunchKernelGGL(small_cross_mean_kernel<false>, dim3(ga), dim3(256), 0, h->stream, X, alpha, (long long)N,
-                       (long long)Np, D, P, l, sf2, ym, ys, Xq, (int)M, Ks, pmean, h->d_count, mean_out);
+    hipLaunchKernelGGL(small_cross_mean_kernel<false>, dim3(ga, B), dim3(256), 0, h->stream, k, (long long)N, (long long)Np,
+                       D, P, Xq, (int)M, Ks, pmean, h->d_count, mean_out);
     GPK_LAUNCH_CHECK(h);
     if (M <= 16)
-      hipLaunchKernelGGL(small_var_kernel<1>, dim3(gb), dim3(64 * VW), 0, h->stream, W, (long long)ldw, (long long)Np,
-                         Ks, (int)M, P, kss, floor_, ym, ys, pmean, ga, pvar, h->d_count + 1, mean_out, var_out);
+      hipLaunchKernelGGL(small_var_kernel<1>, dim3(gb, B), dim3(64 * VW), 0, h->stream, k, (long long)ldw, (long long)Np, Ks,
+                         (int)M, P, floor_, pmean, ga, pvar, h->d_count + GPK_SMALL_MAX_MODELS, mean_out, var_out);
     else
-      hipLaunchKernelGGL(small_var_kernel<2>, dim3(gb), dim3(64 * VW), 0, h->stream, W, (long long)ldw, (long long)Np,
-                         Ks, (int)M, P, kss, floor_, ym, ys, pmean, ga, pvar, h->d_count + 1, mean_out, var_out);
+      hipLaunchKernelGGL(small_var_kernel<2>, dim3(gb, B), dim3(64 * VW), 0, h->stream, k, (long long)ldw, (long long)Np, Ks,
+                         (int)M, P, floor_, pmean, ga, pvar, h->d_count + GPK_SMALL_MAX_MODELS, mean_out, var_out);
   } else {
-    hipLaunchKernelGGL(small_cross_mean_kernel<true>, dim3(ga), dim3(256), 0, h->stream, X, alpha, (long long)N,
-                       (long long)Np, D, P, l, sf2, ym, ys, Xq, (int)M, (double*)nullptr, pmean, h->d_count, mean_out);
+    hipLaunchKernelGGL(small_cross_mean_kernel<true>, dim3(ga, B), dim3(256), 0, h->stream, k, (long long)N, (long long)Np,
+                       D, P, Xq, (int)M, (double*)nullptr, pmean, h->d_count, mean_out);
   }
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;

@@ -188,17 +188,25 @@ class PreTrainedGP:
         if not self.is_loaded:
             return np.zeros((len(X), 6)), np.ones((len(X), 6)) * 1e6
         fused = self._fused()
-        if fused and not return_std:
+        if fused:
+            # models written by `GPTrainer` share scaler and inputs: all of them in one call (<= 32 rows: one C call
+            # and two launches for means and stds, `gpk_predict_host_multi`; larger batches: one fused mean launch)
             bg, names = fused
-            mean = np.zeros((len(X), 6))
             try:
-                ms = bg.predict(self.scalers_X[names[0]].transform(X))
+                out = bg.predict(self.scalers_X[names[0]].transform(X), return_std=return_std)
+                ms, ss = out if return_std else (out, None)
+                mean = np.zeros((len(X), 6))
+                std = np.full((len(X), 6), 1e6) if return_std else None
                 for j, n in enumerate(names):
-                    mean[:, OUTPUT_NAMES.index(n)] = self.scalers_y[n].inverse_transform(ms[:, j].reshape(-1, 1)).ravel()
-                return mean, None
+                    i = OUTPUT_NAMES.index(n)
+                    mean[:, i] = self.scalers_y[n].inverse_transform(ms[:, j].reshape(-1, 1)).ravel()
+                    if return_std:
+                        std[:, i] = np.abs(ss[:, j] * self.scalers_y[n].scale_[0])
+                return mean, std
             except Exception as e:  # noqa: BLE001
                 print(f"GP prediction failed: {e}")
-                return np.zeros((len(X), 6)), None
+                if not return_std:
+                    return np.zeros((len(X), 6)), None
         mean = np.zeros((len(X), 6))
         std = np.full((len(X), 6), 1e6)
         for i, name in enumerate(OUTPUT_NAMES):
