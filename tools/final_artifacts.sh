@@ -37,4 +37,4 @@ python -u tools/run_configs.py > $out/run_configs.log 2>&1; echo "run_configs rc
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "torchrun rc=$?"
 # control-loop latency (one row / horizon-25 through the estimator and the bare C call) and the randomised parity sweep
 timeout -k 10 200 python -u tools/exp_host_overhead.py 2>&1 | grep -v amdgpu.ids > $out/serving_latency.txt; echo "latency rc=$?"; head -8 $out/serving_latency.txt
-(FUZZ_SEED=0 FUZZ_CASES=150 timeout -k 10 400 python -u tools/fuzz_parity.py && FUZZ_SEED=1 FUZZ_CASES=100 timeout -k 10 400 python -u tools/fuzz_parity.py && FUZZ_SEED=2 FUZZ_CASES=50 FUZZ_MAX_N=7000 timeout -k 10 400 python -u tools/fuzz_parity.py) 2>&1 | grep -v amdgpu.ids > $out/fuzz_parity.log; echo "fuzz rc=$?"; grep "cases," $out/fuzz_parity.log
+(FUZZ_SEED=0 FUZZ_CASES=150 timeout -k 10 400 python -u tools/fuzz_parity.py && FUZZ_SEED=1 FUZZ_CASES=100 timeout -k 10 400 python -u tools/fuzz_parity.py && FUZZ_SEED=2 FUZZ_CASES=50 FUZZ_MAX_N=7000 timeout -k 10 400 python -u tools/fuzz_parity.py) 2>&1 | grep -v amdgpu.ids > $out/fuzz_parity.log; echo "fuzz rc=$?"; grep "cases, " $out/fuzz_parity.log

@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from oracle import gp_oracle as O  # noqa: E402
-from unmanned_aerial_vehicles_amd import GaussianProcess, RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel  # noqa: E402
+from unmanned_aerial_vehicles_amd import BatchedARDGP, GaussianProcess, RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel  # noqa: E402
 
 cases = int(os.environ.get("FUZZ_CASES", "150"))
 seed = int(os.environ.get("FUZZ_SEED", "0"))
@@ -105,5 +105,34 @@ for c in range(pk_cases):
         ok = e_mean < 1e-8 and e_var < 1e-7 and e_lml < 1e-9 and v.shape == (M, P)
     bad += not ok
     print(("ok   " if ok else "FAIL ") + tag + f"  mean {e_mean:.1e} var {e_var:.1e} lml {e_lml:.1e}", flush=True)
-print(f"{cases} + {pk_cases} cases, {bad} failures, {time.time() - t0:.0f} s")
+# ---- per-axis ARD GPs served together (gp_trainer.py / pretrained_gp.py): <= 32 rows take gpk_predict_host_multi
+ba_cases = int(os.environ.get("FUZZ_BATCHED_CASES", str(max(cases // 5, 1))))
+for c in range(ba_cases):
+    N, M = max(pick(min(max_n, 2500)), 3), int(rng.integers(1, 41))
+    D, B = int(rng.integers(1, 17)), int(rng.integers(2, 9))
+    X = rng.standard_normal((N, D)); Y = np.sin(X @ rng.standard_normal((D, B))) + 0.1 * rng.standard_normal((N, B))
+    Xq = rng.standard_normal((M, D))
+    normalize = bool(rng.random() < 0.5)
+    tag = f"batched case {c}: N={N} M={M} D={D} B={B} norm={normalize}"
+    bg = BatchedARDGP(length_scale=np.full(D, np.sqrt(D)), noise_level=0.05, alpha=1e-8, normalize_y=normalize, optimizer=None).fit(X, Y)
+    lss, noises = [], []
+    for m in bg.models:                       # distinct hyper-parameters per model
+        th = m.kernel_.theta + rng.uniform(-0.4, 0.4, m.kernel_.theta.shape)
+        m.kernel_.theta = th
+        m._refactor()
+        comp = m.kernel_.components()
+        lss.append(comp.ls_vector(D)); noises.append(comp.noise)
+    bg._fused = None
+    mean, std = bg.predict(Xq, return_std=True)
+    mean_only = bg.predict(Xq)
+    e_mean = e_std = 0.0
+    for b in range(B):
+        st = O.fit_fixed(X, Y[:, b], lss[b], 1.0, noises[b], 1e-8, normalize)
+        om, os_ = O.predict(st, Xq, return_std=True)
+        e_mean, e_std = max(e_mean, rel(mean[:, b], om.ravel())), max(e_std, rel(std[:, b], os_.ravel()))
+    used = M <= 32 and bg._serve is not None and bg._serve.get("ok", False)
+    ok = e_mean < 1e-8 and e_std < 1e-7 and np.array_equal(mean_only, mean) and (used or M > 32)
+    bad += not ok
+    print(("ok   " if ok else "FAIL ") + tag + f"  mean {e_mean:.1e} std {e_std:.1e} one-call path {used}", flush=True)
+print(f"{cases} + {pk_cases} + {ba_cases} cases, {bad} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
