@@ -68,6 +68,44 @@ int main(void) {
   if (!(emax < 1e-10)) return 5;
   if (!(vmin >= 0.0 && vmax < 2.0 * s && vmin > 0.5 * s)) return 6;
 
+  /* the one-call serving entry points: host queries in, host results out (5 rows -> the two-launch small-batch
+   * kernels), one model with P outputs and two single-output models in one call */
+  {
+    const int64_t M = 5;
+    double hm[5 * 2], hv[5], mm[2 * 5], mv[2 * 5];
+    CHECK_GPK(gpk_predict_host(h, dX, dalpha, N, D, P, ls, sf2, zero, one, dW, Np, Np, sf2 + s, 0.0, X, M, hm, hv));
+    double e1 = 0.0, e2 = 0.0;
+    for (int64_t i = 0; i < M * P; ++i) e1 = fmax(e1, fabs(hm[i] - mean[i]));
+    for (int64_t i = 0; i < M; ++i) e2 = fmax(e2, fabs(hv[i] - var[i]));
+    printf("gpk_predict_host vs the device chain: mean %.2e var %.2e\n", e1, e2);
+    if (!(e1 < 1e-11 && e2 < 1e-11)) return 8;
+    double *da0, *da1, *dy0, *dy1;
+    double* ycol = (double*)malloc(sizeof(double) * N);
+    CHECK_HIP(hipMalloc((void**)&da0, sizeof(double) * N)); CHECK_HIP(hipMalloc((void**)&da1, sizeof(double) * N));
+    CHECK_HIP(hipMalloc((void**)&dy0, sizeof(double) * N)); CHECK_HIP(hipMalloc((void**)&dy1, sizeof(double) * N));
+    for (int64_t i = 0; i < N; ++i) ycol[i] = Y[i * P];
+    CHECK_HIP(hipMemcpy(dy0, ycol, sizeof(double) * N, hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < N; ++i) ycol[i] = Y[i * P + 1];
+    CHECK_HIP(hipMemcpy(dy1, ycol, sizeof(double) * N, hipMemcpyHostToDevice));
+    CHECK_GPK(gpk_potrs(h, dK, Np, Np, dwinv, dy0, N, 1, da0));
+    CHECK_GPK(gpk_potrs(h, dK, Np, Np, dwinv, dy1, N, 1, da1));
+    const double* Xs[2] = {dX, dX};
+    const double* As[2] = {da0, da1};
+    const double* Ws[2] = {dW, dW};
+    const double ls2[6] = {0.9, 1.1, 1.3, 0.9, 1.1, 1.3}, sf22[2] = {sf2, sf2}, kss2[2] = {sf2 + s, sf2 + s};
+    CHECK_GPK(gpk_predict_host_multi(h, 2, Xs, As, N, D, ls2, sf22, zero, one, Ws, Np, Np, kss2, 0.0, X, M, mm, mv));
+    double e3 = 0.0, e4 = 0.0;
+    for (int b = 0; b < 2; ++b)
+      for (int64_t i = 0; i < M; ++i) {
+        e3 = fmax(e3, fabs(mm[b * M + i] - mean[i * P + b]));
+        e4 = fmax(e4, fabs(mv[b * M + i] - var[i]));
+      }
+    printf("gpk_predict_host_multi (2 models) vs the device chain: mean %.2e var %.2e\n", e3, e4);
+    if (!(e3 < 1e-11 && e4 < 1e-11)) return 9;
+    if (gpk_predict_host_multi(h, 2, Xs, As, N, D, ls2, sf22, zero, one, Ws, Np, Np, kss2, 0.0, X, 33, mm, mv) != GPK_BAD_ARG) return 10;
+    if (gpk_predict_host_multi(h, 9, Xs, As, N, D, ls2, sf22, zero, one, Ws, Np, Np, kss2, 0.0, X, M, mm, mv) != GPK_BAD_ARG) return 11;
+  }
+
   /* not positive definite: a Gram matrix with a negative "noise" large enough to break it */
   CHECK_GPK(gpk_gram(h, GPK_F64, dX, N, D, ls, sf2, -sf2 - 1.0, dK, Np));
   const int rc = gpk_potrf(h, dK, Np, Np, dwinv, &info);
