@@ -18,7 +18,10 @@ dev = DeviceGP(X, np.zeros((N, 1)), be)
 dev.gram(2.0, 1.0, 0.1001)
 torch.cuda.synchronize()
 print("POTRF_BEGIN", file=sys.stderr, flush=True)
-dev.factorize(2.0, 1.0, 0.1001)
+try:
+    dev.factorize(2.0, 1.0, 0.1001)
+except Exception as e:  # noqa: BLE001  (skip-variant builds of the leaf kernel produce garbage)
+    print("factorize:", e)
 torch.cuda.synchronize()
 print("POTRF_END", file=sys.stderr, flush=True)
 if len(sys.argv) > 2:

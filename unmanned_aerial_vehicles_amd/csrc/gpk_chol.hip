@@ -17,24 +17,28 @@ constexpr int NB = 128;       // leaf size
 // The block lives in LDS (row stride 130 doubles: conflict-free ds_read_b64 for the MFMA operand
 // pattern row = lane & 15, k = lane >> 4).  Blocked left-looking sweep with 16 x 16 sub-blocks:
 //   P1  block column jb  -= L[ib, 0:jb] L[jb, 0:jb]^T          fp64 MFMA 16x16x4, one block per wave
-//   P2  16 x 16 diagonal block: unblocked right-looking factorisation (256 threads, one per element)
-//   P3  rows below: x L_jj^T = a by substitution, one thread per row; 16 extra threads solve the
-//       identity rows, which yields W_jj^T = L_jj^-T for the inverse
+//   P2  16 x 16 diagonal block AND its inverse by one wave: a row per lane (16 block rows + 16 identity rows) in
+//       registers, right-looking sweep with the pivot column broadcast by v_readlane (no LDS in the loop)
+//   P3  rows below: X = A W_jj^T on the MFMA (the solve x L_jj^T = a through the explicit 16 x 16 inverse)
 // then the inverse W = L^-1 block diagonal by block diagonal on the MFMA:
 //   W_ij = -W_ii (sum_{k=j}^{i-1} L_ik W_kj),   i - j = 1 .. 7
 // The inner sum's accumulator is used directly as the B operand of the second product (the f64
 // C/D map row = (lane >> 4) + 4 reg is exactly the B-operand map of k-step reg).  Off-diagonal W
 // blocks are parked transposed in the (otherwise unused) upper triangle of the LDS image.
 // FACTOR == false: the block already holds a factor (imported model); only W is produced.
+#ifndef GPK_LEAF_SKIP
+#define GPK_LEAF_SKIP 0     // timing experiments only (tools/exp_leaf_time.sh): bit 0 skips P1, 1 P2, 2 P3, 3 the inverse; results are then wrong
+#endif
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int LSA = 130;   // LDS row stride of the 128 x 128 image
 constexpr int LSW = 18;    // row stride of the 16 x 16 diagonal inverses
 
-// order the LDS traffic of ONE wave (its ds operations execute in order; this only stops the compiler from
-// moving them across)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+// value of `x` in lane `src` (compile-time constant after unrolling) as a wave-uniform scalar: two v_readlane_b32
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, src);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 template <bool FACTOR>
@@ -47,12 +51,27 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
   int* __restrict__ info = info0 + blockIdx.x;
   __shared__ __attribute__((aligned(16))) double a[NB * LSA];
   __shared__ __attribute__((aligned(16))) double wd[8 * 16 * LSW];   // wd[b][r][c] = W_bb[c][r]
-  __shared__ double colbuf[32];    // P2: current column / 1 / L_cc (0..15) and L_cc (16..31) of the diagonal block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    a[i * LSA + j] = (j <= i) ? A[(long long)i * lda + j] : 0.0;
+  // The block comes in as 16-byte pieces, all 32 loads of a thread in flight at once (the kernel is one workgroup on
+  // one CU: its cost is latency, and 64 dependent 8-byte round trips were a third of it).  The strictly upper part is
+  // read too (valid memory: K is symmetric there) and zeroed on the way into LDS.
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  {
+    dv2 buf[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, j = (e & 63) * 2;
+      buf[u] = *reinterpret_cast<const dv2*>(A + (long long)i * lda + j);
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, j = (e & 63) * 2;
+      dv2 v = buf[u];
+      if (j > i) v.x = 0.0;
+      if (j + 1 > i) v.y = 0.0;
+      *reinterpret_cast<dv2*>(a + i * LSA + j) = v;
+    }
   }
   __syncthreads();
 
@@ -60,7 +79,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
     const int c0 = 16 * jb;
     if (FACTOR) {
       // ---- P1: left-looking update of block column jb
-      if (jb > 0) {
+      if (jb > 0 && !(GPK_LEAF_SKIP & 1)) {
         for (int ib = jb + wave; ib < 8; ib += 4) {
           d4 acc;
 #pragma unroll
@@ -78,90 +97,107 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
         }
         __syncthreads();
       }
-      // ---- P2: unblocked factorisation of the 16 x 16 diagonal block by ONE wave, its lower triangle in
-      // registers (lane = (row i, column group kq): columns kq, kq + 4, kq + 8, kq + 12).  Each of the 16
-      // column steps publishes the current column through a 16-entry LDS buffer; a wave's LDS operations
-      // complete in order, so no workgroup barrier is needed inside the loop.  Columns stay unscaled
-      // (a_ik -= a_ic a_kc / d) until the final scaling by 1 / sqrt(pivot), which also leaves the
-      // reciprocal diagonal for P3.
-      if (wave == 0) {
-        const int i = lane & 15, kq = lane >> 4;
-        double v[4];
+    }
+    // ---- P2: the 16 x 16 diagonal block AND its inverse by ONE wave, without touching LDS inside the loop: lane i
+    // (0..15) holds row i of the block in 16 registers, lane 16 + r the identity row e_r.  Right-looking sweep with
+    // unscaled columns, a_ik -= (a_ic / d_c) a_kc: every quantity a step needs from another row (the pivot d_c and
+    // the column entries a_kc) is a v_readlane broadcast into scalar registers.  The identity rows undergo the
+    // same updates (x L_jj^T = e_r by substitution), which yields W_jj^T = L_jj^-T.  One final scaling of the
+    // columns by 1 / sqrt(d_c) turns both into L_jj and W_jj^T (d_c / sqrt(d_c) = sqrt(d_c) on the diagonal).
+    // Entries above the diagonal of the block rows are never read.
+    if (wave == 0 && !(GPK_LEAF_SKIP & 2)) {
+      const int i = lane & 15;
+      const bool blk = lane < 16, idn = lane >= 16 && lane < 32;
+      double v[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = a[(c0 + i) * LSA + c0 + kq + 4 * r];
+      for (int c = 0; c < 16; ++c) {
+        const double l = a[(c0 + i) * LSA + c0 + c];
+        v[c] = blk ? ((c <= i) ? l : 0.0) : ((idn && c == i) ? 1.0 : 0.0);
+      }
+      if (FACTOR) {
+        // One straight-line block for the whole sweep (no branches: a failed pivot is handled by selects and
+        // reported once at the end), ordered so that the next pivot's reciprocal - the loop-carried chain
+        // v_rcp_f64 + two Newton steps, error ~1e-16 - is issued right after the one update it depends on and
+        // runs under the remaining, independent updates of the current column.
+        int bad = 0;                             // 1-based column of the first non-positive pivot
+        double d = lane_bcast(v[0], 0);
+        bad = (!(d > 0.0) && bad == 0) ? 1 : bad;
+        if (lane == 0) v[0] = (d > 0.0) ? v[0] : 1.0;
+        d = (d > 0.0) ? d : 1.0;
+        double rd = __builtin_amdgcn_rcp(d);
+        rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+        rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          if (kq == (c & 3)) colbuf[i] = v[c >> 2];
-          wave_lds_sync();
-          // all six values in one batch of LDS reads and branch-free selects below (with the updates under
-          // branches the compiler sinks each read into its branch: six serialised LDS round trips per step)
-          double d = colbuf[c];
-          const double ci = colbuf[i];
-          double ck[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ck[r] = colbuf[kq + 4 * r];
-          if (!(d > 0.0)) {                      // not positive definite (or NaN): record, stay finite
-            if (lane == 0) atomicCAS(info, 0, row0 + c0 + c + 1);
-            d = 1.0;
+          const double f = v[c] * rd;
+          if (c + 1 < 16) {
+            v[c + 1] = __builtin_fma(-f, lane_bcast(v[c], c + 1), v[c + 1]);
+            d = lane_bcast(v[c + 1], c + 1);     // the next pivot is final now
+            bad = (!(d > 0.0) && bad == 0) ? c + 2 : bad;
+            if (lane == c + 1) v[c + 1] = (d > 0.0) ? v[c + 1] : 1.0;
+            d = (d > 0.0) ? d : 1.0;
+            rd = __builtin_amdgcn_rcp(d);
+            rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+            rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
           }
-          // 1 / d by v_rcp_f64 + two Newton steps (error ~1e-16): the division is on the loop's critical path
-          double rd = __builtin_amdgcn_rcp(d);
-          rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
-          rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
-          const double f = ci * rd;
+          double sk[16];                          // column c as scalars, read ahead of the updates that use them
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int k = kq + 4 * r;
-            const double u = __builtin_fma(-f, ck[r], v[r]);
-            v[r] = (i > c && k > c && k <= i) ? u : v[r];
+          for (int k = c + 2; k < 16; ++k) sk[k] = lane_bcast(v[c], k);
+#pragma unroll
+          for (int k = c + 2; k < 16; ++k) v[k] = __builtin_fma(-f, sk[k], v[k]);
+        }
+        if (bad != 0 && lane == 0) atomicCAS(info, 0, row0 + c0 + bad);   // not positive definite (or NaN)
+        double pv = 1.0;                         // lane c (< 16): its own pivot d_c
+#pragma unroll
+        for (int c = 0; c < 16; ++c) pv = (i == c) ? v[c] : pv;
+        const double rs = 1.0 / __builtin_sqrt(pv);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] *= lane_bcast(rs, c);
+      } else {
+        // the block already holds L_jj: only the identity rows are solved, x_c /= L_cc, x_k -= x_c L_kc
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double lcc = lane_bcast(v[c], c);
+          const double xc = v[c] / lcc;
+          if (idn) v[c] = xc;
+#pragma unroll
+          for (int k = c + 1; k < 16; ++k) {
+            const double u = __builtin_fma(-xc, lane_bcast(v[c], k), v[k]);   // L_kc from lane k
+            if (idn) v[k] = u;
           }
-          wave_lds_sync();
-        }
-        if (kq == (i & 3)) {
-          double pv = v[i >> 2];
-          if (!(pv > 0.0)) pv = 1.0;
-          const double sq = __builtin_sqrt(pv);
-          colbuf[i] = 1.0 / sq;
-          colbuf[16 + i] = sq;
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = kq + 4 * r;
-          if (k < i) a[(c0 + i) * LSA + c0 + k] = v[r] * colbuf[k];
-          else if (k == i) a[(c0 + i) * LSA + c0 + k] = colbuf[16 + i];
         }
       }
-      __syncthreads();
-    }
-    // ---- P3: panel rows x L_jj^T = a (threads 0..111) and identity rows -> W_jj^T (threads 112..127)
-    if (tid < 128) {
-      const bool ident = tid >= 112;
-      const int row = ident ? (tid - 112) : (c0 + 16 + tid);
-      if (ident || (FACTOR && row < NB)) {
-        double x[16];
+      if (blk && FACTOR) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = ident ? ((c == row) ? 1.0 : 0.0) : a[row * LSA + c0 + c];
+        for (int c = 0; c < 16; ++c)
+          if (c <= i) a[(c0 + i) * LSA + c0 + c] = v[c];
+      }
+      if (idn) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          x[c] = FACTOR ? x[c] * colbuf[c] : x[c] / a[(c0 + c) * LSA + c0 + c];
-#pragma unroll
-          for (int c2 = c + 1; c2 < 16; ++c2) x[c2] = __builtin_fma(-x[c], a[(c0 + c2) * LSA + c0 + c], x[c2]);
-        }
-        if (ident) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) wd[(jb * 16 + row) * LSW + c] = x[c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) a[row * LSA + c0 + c] = x[c];
-        }
+        for (int c = 0; c < 16; ++c) wd[(jb * 16 + i) * LSW + c] = v[c];
       }
     }
     __syncthreads();
+    // ---- P3: the panel below the diagonal block, X = A W_jj^T (the solve x L_jj^T = a through the explicit
+    // inverse), one 16 x 16 block per wave on the MFMA
+    if (FACTOR && !(GPK_LEAF_SKIP & 4)) {
+      for (int ib = jb + 1 + wave; ib < 8; ib += 4) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double av = a[(16 * ib + lr) * LSA + c0 + 4 * s4 + lq];          // A[r][k]
+          const double bv = wd[(jb * 16 + 4 * s4 + lq) * LSW + lr];              // W_jj[c][k] = wd[jb][k][c]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[(16 * ib + lq + 4 * r) * LSA + c0 + lr] = acc[r];
+      }
+      __syncthreads();
+    }
   }
 
   // ---- inverse, block diagonal by block diagonal
-  for (int d = 1; d < 8; ++d) {
+  for (int d = 1; d < ((GPK_LEAF_SKIP & 8) ? 1 : 8); ++d) {
     for (int i = d + wave; i < 8; i += 4) {
       const int j = i - d;
       d4 S = {0.0, 0.0, 0.0, 0.0};
@@ -186,14 +222,23 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
     __syncthreads();
   }
 
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    if (FACTOR && j <= i) A[(long long)i * lda + j] = a[i * LSA + j];
-    const int bi = i >> 4, bj = j >> 4;
-    double w = 0.0;
-    if (bi > bj) w = a[(16 * bj + (j & 15)) * LSA + 16 * bi + (i & 15)];
-    else if (bi == bj) w = wd[(bi * 16 + (j & 15)) * LSW + (i & 15)];
-    W[i * NB + j] = w;
+#pragma unroll 8
+  for (int u = 0; u < 32; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, j = (e & 63) * 2;        // entries (i, j) and (i, j + 1), j even
+    if (FACTOR) {                                                        // the factor: lower triangle only
+      if (j + 1 <= i) *reinterpret_cast<dv2*>(A + (long long)i * lda + j) = *reinterpret_cast<const dv2*>(a + i * LSA + j);
+      else if (j == i) A[(long long)i * lda + j] = a[i * LSA + j];
+    }
+    const int bi = i >> 4, bj = j >> 4, il = i & 15, jl = j & 15;
+    dv2 w = {0.0, 0.0};
+    if (bi > bj) {
+      w.x = a[(16 * bj + jl) * LSA + 16 * bi + il];
+      w.y = a[(16 * bj + jl + 1) * LSA + 16 * bi + il];
+    } else if (bi == bj) {
+      w.x = wd[(bi * 16 + jl) * LSW + il];
+      w.y = wd[(bi * 16 + jl + 1) * LSW + il];
+    }
+    *reinterpret_cast<dv2*>(W + i * NB + j) = w;
   }
 }
 
@@ -357,6 +402,7 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, doubl
   GPK_REQUIRE(h, A && winv && info, "potrf: null pointer");
   GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && lda >= Np && lda % 2 == 0, "potrf: Np must be a positive multiple of 128");
   GPK_REQUIRE(h, Np < (1ll << 31), "potrf: Np too large");
+  GPK_REQUIRE(h, ((uintptr_t)A % 16) == 0 && ((uintptr_t)winv % 16) == 0, "potrf: A, winv must be 16-byte aligned");
   const int nb = h->batch;                         // batched mode: info receives one entry per problem
   GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, nb * sizeof(int), h->stream));
   GPK_TRY(potrf_rec(h, A, lda, Np, winv, 0));
@@ -381,6 +427,7 @@ extern "C" int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int6
   if (!h) return GPK_BAD_ARG;
   GPK_REQUIRE(h, L && winv, "leaf_inverses: null pointer");
   GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && ldl >= Np, "leaf_inverses: Np must be a positive multiple of 128");
+  GPK_REQUIRE(h, ldl % 2 == 0 && ((uintptr_t)L % 16) == 0 && ((uintptr_t)winv % 16) == 0, "leaf_inverses: L, winv must be 16-byte aligned, ldl even");
   for (int64_t b = 0; b < Np / NB; ++b) {
     hipLaunchKernelGGL(leaf_kernel<false>, dim3(h->batch), dim3(256), 0, h->stream,
                        const_cast<double*>(L) + b * NB * ldl + b * NB, (long long)ldl, 0, h->d_info,
