@@ -301,6 +301,107 @@ __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict
   if (tid == 0) out[b] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- 256-wide base case of the right-hand triangular solve, one launch:
+//   [B1 B2] <- [B1 B2] inv(L)^T  for the 256 x 256 lower block L = [L11 0; L21 L22] with inverse leaves W1, W2:
+//   X1 = B1 W1^T;   X2 = (B2 - X1 L21^T) W2^T.
+// The recursion spent three launches here (leaf product, 128-deep update, leaf product), each of them bound by
+// ONE CU's fp64 MFMA rate per 128-row tile or, for tall panels, by eight short dependent k-steps per workgroup.  Here a
+// workgroup owns 32 rows (4x the workgroups) and chains the three products: every operand is read straight from
+// L2 as k-contiguous 16-byte pieces (no LDS staging, as in gpk_small.hip), the intermediate 32 x 128 result
+// passes through LDS to become the next product's A operand.  In place: a workgroup reads only its own rows.
+constexpr int TR = 32;
+typedef double dv2t __attribute__((ext_vector_type(2)));
+
+// acc[rb][cb] += sum_k A[16 rb + i][k] * Bm[n][k] over k = 0..127, wave-private 32 x 32 block (2 x 2 MFMA blocks).
+// ap: this lane's row (i) of the A operand for rb = 0 (+ 16 rows for rb = 1), already offset by 2 kq;
+// bp: this lane's row n of Bm for cb = 0 (+ 16 rows for cb = 1), already offset by 2 kq.  NEG: subtract.
+template <bool NEG>
+__device__ __forceinline__ void chain_product(const double* ap, long long a_rs, const double* bp, long long b_rs,
+                                              d4 (&acc)[2][2]) {
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {                      // two halves of k: 8 steps of 8 k each
+    dv2t a[2][8], b[2][8];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        a[x][s] = *reinterpret_cast<const dv2t*>(ap + x * 16 * a_rs + 64 * hh + 8 * s);
+        b[x][s] = *reinterpret_cast<const dv2t*>(bp + x * 16 * b_rs + 64 * hh + 8 * s);
+      }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const double ax = NEG ? -a[rb][s].x : a[rb][s].x, ay = NEG ? -a[rb][s].y : a[rb][s].y;
+          acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[cb][s].x, acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b[cb][s].y, acc[rb][cb], 0, 0, 0);
+        }
+  }
+}
+
+__global__ __launch_bounds__(256) void trsm256_kernel(double* __restrict__ B0, long long ldb,
+                                                      const double* __restrict__ L0, long long ldl,
+                                                      const double* __restrict__ W0, long long strideB,
+                                                      long long strideL, long long strideW) {
+  constexpr int XS = 130;                               // LDS row stride: conflict-free 16-byte operand reads
+  __shared__ __attribute__((aligned(16))) double xs[TR * XS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kq = lane >> 4;
+  double* B = reinterpret_cast<double*>(reinterpret_cast<char*>(B0) + blockIdx.y * strideB) + (long long)blockIdx.x * TR * ldb;
+  const double* L = reinterpret_cast<const double*>(reinterpret_cast<const char*>(L0) + blockIdx.y * strideL);
+  const double* W = reinterpret_cast<const double*>(reinterpret_cast<const char*>(W0) + blockIdx.y * strideW);
+  const int c0 = 32 * w;                                // this wave's 32 output columns
+  d4 acc[2][2];
+  // accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg
+  auto zero = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = d4{0.0, 0.0, 0.0, 0.0};
+  };
+  auto to_lds = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[(16 * rb + kq + 4 * r) * XS + c0 + 16 * cb + i] = acc[rb][cb][r];
+  };
+  // X1 = B1 W1^T
+  zero();
+  chain_product<false>(B + (long long)i * ldb + 2 * kq, ldb, W + (long long)(c0 + i) * NB + 2 * kq, NB, acc);
+  __syncthreads();                                      // every wave has read B1 (all 128 columns) before it changes
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) B[(long long)(16 * rb + kq + 4 * r) * ldb + c0 + 16 * cb + i] = acc[rb][cb][r];
+  to_lds();
+  __syncthreads();
+  // T = B2 - X1 L21^T
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rb][cb][r] = B[(long long)(16 * rb + kq + 4 * r) * ldb + NB + c0 + 16 * cb + i];
+  chain_product<true>(xs + i * XS + 2 * kq, XS, L + (long long)(NB + c0 + i) * ldl + 2 * kq, ldl, acc);
+  __syncthreads();                                      // X1 has been consumed: the buffer takes T
+  to_lds();
+  __syncthreads();
+  // X2 = T W2^T
+  zero();
+  chain_product<false>(xs + i * XS + 2 * kq, XS, W + (long long)(NB + c0 + i) * NB + 2 * kq, NB, acc);
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) B[(long long)(16 * rb + kq + 4 * r) * ldb + NB + c0 + 16 * cb + i] = acc[rb][cb][r];
+}
+
 inline int half_split(int64_t n) { return (int)(((n / NB) / 2) * NB); }
 
 template <typename T> constexpr int dt();
@@ -313,6 +414,12 @@ int trsm_right_rec(gpk_handle h, double* B, int64_t ldb, int64_t m, const double
   if (n == NB) {
     GemmArgs g = gemm_args(B, ldb, 0, winv, NB, 0, B, ldb, (int)m, NB, NB, 1.0, 0.0);
     return gpk_gemm(h, GPK_F64, g);
+  }
+  if (n == 2 * NB && h->trsm256) {                      // two leaves and the update between them: one launch
+    hipLaunchKernelGGL(trsm256_kernel, dim3((unsigned)(m / TR), h->batch), dim3(256), 0, h->stream, B, (long long)ldb, L,
+                       (long long)ldl, winv, gpk_bstride(h, B), gpk_bstride(h, L), gpk_bstride(h, winv));
+    GPK_LAUNCH_CHECK(h);
+    return GPK_OK;
   }
   const int64_t n1 = half_split(n), n2 = n - n1;
   GPK_TRY(trsm_right_rec(h, B, ldb, m, L, ldl, n1, winv));

@@ -31,6 +31,7 @@ struct gpk_context {
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 128;
+  int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
