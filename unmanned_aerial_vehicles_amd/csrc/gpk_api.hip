@@ -31,6 +31,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_K5_SUPER")) h->k5_super = atoi(e);
   if (const char* e = getenv("GPK_SMALL_PATH")) h->small_path = atoi(e);
   if (const char* e = getenv("GPK_TRSM256")) h->trsm256 = atoi(e);
+  if (const char* e = getenv("GPK_TRTRI_LEVELS")) h->trtri_levels = atoi(e);
   if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
   *out = h;
   return GPK_OK;

@@ -477,6 +477,11 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
   p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
   p.sA = gpk_bstride(h, g.A); p.sB = gpk_bstride(h, g.B); p.sC = gpk_bstride(h, g.C);
+  unsigned ny = (unsigned)h->batch;
+  if (g.nbatch > 0) {
+    if (h->batch != 1) { h->err = "gemm: explicit batches are not available in batched mode"; return GPK_BAD_ARG; }
+    ny = (unsigned)g.nbatch; p.sA = g.sA; p.sB = g.sB; p.sC = g.sC;
+  }
   p.m = g.m; p.n = g.n; p.k = g.k;
   p.alpha = g.alpha; p.beta = g.beta;
   p.lower_only = g.lower_only; p.kb0 = g.kb0; p.kb_row = g.kb_row; p.kb_col = g.kb_col;
@@ -499,7 +504,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
   p.k_super = (g.k_super && 2 * p.sr * (TS / 64) <= 2 * GPK_ZERO_BAND_TILES) ? 1 : 0;
   const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
   if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
-  dim3 grid((unsigned)nblocks, (unsigned)h->batch), block(WM * 128);
+  dim3 grid((unsigned)nblocks, ny), block(WM * 128);
   if (g.epilogue == 1) {
     if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }
     if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1, WM, TS>), grid, block, 0, h->stream, p);
@@ -519,7 +524,8 @@ int launch(gpk_handle h, const GemmArgs& g) {
 
 // tile edge gpk_gemm will use for this launch (callers that size per-tile-row outputs need it)
 int gpk_gemm_tile(gpk_handle h, const GemmArgs& g) {
-  const long long t128 = g.lower_only ? (long long)(g.m / 128) * (g.m / 128 + 1) / 2 : (long long)(g.m / 128) * (g.n / 128);
+  long long t128 = g.lower_only ? (long long)(g.m / 128) * (g.m / 128 + 1) / 2 : (long long)(g.m / 128) * (g.n / 128);
+  if (g.nbatch > 0) t128 *= g.nbatch;                  // what counts is how many workgroups the launch has
   const bool aliased = g.C == g.A || g.C == g.B;
   return (!aliased && t128 < h->gemm_small_tiles) ? 64 : 128;
 }

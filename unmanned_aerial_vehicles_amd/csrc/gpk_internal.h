@@ -31,6 +31,7 @@ struct gpk_context {
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 128;
+  int trtri_levels = 1;      // gpk_trtri: one batched launch per level for power-of-two tile counts (GPK_TRTRI_LEVELS=0: recursion)
   int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
@@ -111,6 +112,10 @@ struct GemmArgs {
   int k_super;      // every row of an 8-row super-tile takes the k-range of its longest row (the operand must be
                     // zero beyond each row's own range): the 64 workgroups of a super-tile then run in lockstep
   int epilogue;   // 0: store C;  1: C (fp64, ld = ldc) [tile_row][col] = sum over the tile's rows of (alpha*acc)^2
+  // nbatch > 0: that many independent products in one launch (second grid dimension), operand i at base + i * stride
+  // (bytes).  Not combinable with the handle's own batched mode.
+  int nbatch;
+  long long sA, sB, sC;
 };
 inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb,
                           void* C, int64_t ldc, int m, int n, int k, double alpha, double beta) {
@@ -118,6 +123,7 @@ inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.m = m; g.n = n; g.k = k; g.ta = ta; g.tb = tb; g.alpha = alpha; g.beta = beta;
   g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0; g.epilogue = 0; g.heavy_first = 0; g.k_super = 0;
+  g.nbatch = 0; g.sA = 0; g.sB = 0; g.sC = 0;
   return g;
 }
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);
