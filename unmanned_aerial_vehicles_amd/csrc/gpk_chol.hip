@@ -18,7 +18,8 @@ constexpr int NB = 128;       // leaf size
 // pattern row = lane & 15, k = lane >> 4).  Blocked left-looking sweep with 16 x 16 sub-blocks:
 //   P1  block column jb  -= L[ib, 0:jb] L[jb, 0:jb]^T          fp64 MFMA 16x16x4, one block per wave
 //   P2  16 x 16 diagonal block AND its inverse by one wave: a row per lane (16 block rows + 16 identity rows) in
-//       registers, right-looking sweep with the pivot column broadcast by v_readlane (no LDS in the loop)
+//       registers, right-looking sweep with the pivot column broadcast by v_mov_b64_dpp row_newbcast (no LDS and no
+//       scalar round trips in the loop)
 //   P3  rows below: X = A W_jj^T on the MFMA (the solve x L_jj^T = a through the explicit 16 x 16 inverse)
 // then the inverse W = L^-1 block diagonal by block diagonal on the MFMA:
 //   W_ij = -W_ii (sum_{k=j}^{i-1} L_ik W_kj),   i - j = 1 .. 7
@@ -33,12 +34,27 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int LSA = 130;   // LDS row stride of the 128 x 128 image
 constexpr int LSW = 18;    // row stride of the 16 x 16 diagonal inverses
 
-// value of `x` in lane `src` (compile-time constant after unrolling) as a wave-uniform scalar: two v_readlane_b32
-__device__ __forceinline__ double lane_bcast(double x, int src) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, src);
-  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+// value of `x` in lane SRC of the caller's 16-lane DPP row, in every lane of that row: one v_mov_b64_dpp
+// (the DPP control must be a literal for the builtin to keep its 64-bit type inside a template: one case per lane)
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  long long r = 0;
+#define GPK_ROW_NEWBCAST(n) if constexpr (SRC == n) r = __builtin_amdgcn_update_dpp(0ll, b, 0x150 + n, 0xf, 0xf, true);
+  GPK_ROW_NEWBCAST(0) GPK_ROW_NEWBCAST(1) GPK_ROW_NEWBCAST(2) GPK_ROW_NEWBCAST(3) GPK_ROW_NEWBCAST(4) GPK_ROW_NEWBCAST(5)
+  GPK_ROW_NEWBCAST(6) GPK_ROW_NEWBCAST(7) GPK_ROW_NEWBCAST(8) GPK_ROW_NEWBCAST(9) GPK_ROW_NEWBCAST(10) GPK_ROW_NEWBCAST(11)
+  GPK_ROW_NEWBCAST(12) GPK_ROW_NEWBCAST(13) GPK_ROW_NEWBCAST(14) GPK_ROW_NEWBCAST(15)
+#undef GPK_ROW_NEWBCAST
+  static_assert(SRC >= 0 && SRC < 16, "row_newbcast lane");
+  return __builtin_bit_cast(double, r);
+}
+template <int V> struct LeafC { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(LeafC<I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 template <bool FACTOR>
@@ -98,83 +114,91 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
         __syncthreads();
       }
     }
-    // ---- P2: the 16 x 16 diagonal block AND its inverse by ONE wave, without touching LDS inside the loop: lane i
-    // (0..15) holds row i of the block in 16 registers, lane 16 + r the identity row e_r.  Right-looking sweep with
-    // unscaled columns, a_ik -= (a_ic / d_c) a_kc: every quantity a step needs from another row (the pivot d_c and
-    // the column entries a_kc) is a v_readlane broadcast into scalar registers.  The identity rows undergo the
-    // same updates (x L_jj^T = e_r by substitution), which yields W_jj^T = L_jj^-T.  One final scaling of the
-    // columns by 1 / sqrt(d_c) turns both into L_jj and W_jj^T (d_c / sqrt(d_c) = sqrt(d_c) on the diagonal).
-    // Entries above the diagonal of the block rows are never read.
+    // ---- P2: the 16 x 16 diagonal block AND its inverse by ONE wave, in registers, with no LDS and no scalar
+    // round trips inside the loop.  Every 16-lane DPP row holds a copy of the block, lane (i) = row i in 16 registers
+    // (u); row 1 (lanes 16..31) also carries the identity rows e_i (x).  Right-looking sweep with unscaled columns,
+    // a_ik -= (a_ic / d_c) a_kc: what a step needs from another row -- the pivot d_c and the column entries a_kc --
+    // is one v_mov_b64_dpp row_newbcast each (lane k of the own 16-lane row to all its lanes).  The identity rows
+    // undergo the same updates (x L_jj^T = e_r by substitution), which yields W_jj^T = L_jj^-T.  One final scaling
+    // of the columns by 1 / sqrt(d_c) turns both into L_jj and W_jj^T (d_c / sqrt(d_c) = sqrt(d_c) on the diagonal).
+    // Straight-line and branch-free (a failed pivot is handled by selects and reported once); the next pivot's
+    // reciprocal -- v_rcp_f64 + two Newton steps, error ~1e-16, the loop-carried chain -- is issued right after the
+    // one update it depends on.  Entries above the diagonal of the block rows are never read.
     if (wave == 0 && !(GPK_LEAF_SKIP & 2)) {
       const int i = lane & 15;
-      const bool blk = lane < 16, idn = lane >= 16 && lane < 32;
-      double v[16];
+      double u[16], x[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const double l = a[(c0 + i) * LSA + c0 + c];
-        v[c] = blk ? ((c <= i) ? l : 0.0) : ((idn && c == i) ? 1.0 : 0.0);
+        u[c] = (c <= i) ? l : 0.0;
+        x[c] = (c == i) ? 1.0 : 0.0;
       }
       if (FACTOR) {
-        // One straight-line block for the whole sweep (no branches: a failed pivot is handled by selects and
-        // reported once at the end), ordered so that the next pivot's reciprocal - the loop-carried chain
-        // v_rcp_f64 + two Newton steps, error ~1e-16 - is issued right after the one update it depends on and
-        // runs under the remaining, independent updates of the current column.
         int bad = 0;                             // 1-based column of the first non-positive pivot
-        double d = lane_bcast(v[0], 0);
-        bad = (!(d > 0.0) && bad == 0) ? 1 : bad;
-        if (lane == 0) v[0] = (d > 0.0) ? v[0] : 1.0;
-        d = (d > 0.0) ? d : 1.0;
-        double rd = __builtin_amdgcn_rcp(d);
-        rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
-        rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double f = v[c] * rd;
-          if (c + 1 < 16) {
-            v[c + 1] = __builtin_fma(-f, lane_bcast(v[c], c + 1), v[c + 1]);
-            d = lane_bcast(v[c + 1], c + 1);     // the next pivot is final now
-            bad = (!(d > 0.0) && bad == 0) ? c + 2 : bad;
-            if (lane == c + 1) v[c + 1] = (d > 0.0) ? v[c + 1] : 1.0;
-            d = (d > 0.0) ? d : 1.0;
-            rd = __builtin_amdgcn_rcp(d);
-            rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
-            rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+        double d = row_bcast<0>(u[0]), rd;
+        auto pivot = [&](auto cc) {              // d holds the (final) pivot of column C
+          constexpr int C = decltype(cc)::value;
+          const bool ok = d > 0.0;
+          bad = (!ok && bad == 0) ? C + 1 : bad;
+          u[C] = (!ok && i == C) ? 1.0 : u[C];
+          d = ok ? d : 1.0;
+          rd = __builtin_amdgcn_rcp(d);
+          rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+          rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+        };
+        pivot(LeafC<0>{});
+        static_for<0, 16>([&](auto cc) {
+          constexpr int C = decltype(cc)::value;
+          const double nf = -u[C] * rd, ng = -x[C] * rd;
+          if constexpr (C + 1 < 16) {
+            const double s1 = row_bcast<C + 1>(u[C]);
+            u[C + 1] = __builtin_fma(nf, s1, u[C + 1]);
+            x[C + 1] = __builtin_fma(ng, s1, x[C + 1]);
+            d = row_bcast<C + 1>(u[C + 1]);      // the next pivot is final now
+            pivot(LeafC<C + 1>{});
           }
-          double sk[16];                          // column c as scalars, read ahead of the updates that use them
-#pragma unroll
-          for (int k = c + 2; k < 16; ++k) sk[k] = lane_bcast(v[c], k);
-#pragma unroll
-          for (int k = c + 2; k < 16; ++k) v[k] = __builtin_fma(-f, sk[k], v[k]);
-        }
+          double sk[16];                          // column C across the row, read ahead of the updates that use it
+          static_for<C + 2, 16>([&](auto kk) { sk[decltype(kk)::value] = row_bcast<decltype(kk)::value>(u[C]); });
+          static_for<C + 2, 16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            u[K] = __builtin_fma(nf, sk[K], u[K]);
+          });
+          static_for<C + 2, 16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            x[K] = __builtin_fma(ng, sk[K], x[K]);
+          });
+        });
         if (bad != 0 && lane == 0) atomicCAS(info, 0, row0 + c0 + bad);   // not positive definite (or NaN)
-        double pv = 1.0;                         // lane c (< 16): its own pivot d_c
+        double pv = 1.0;                         // lane i: its own pivot d_i
 #pragma unroll
-        for (int c = 0; c < 16; ++c) pv = (i == c) ? v[c] : pv;
+        for (int c = 0; c < 16; ++c) pv = (i == c) ? u[c] : pv;
         const double rs = 1.0 / __builtin_sqrt(pv);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] *= lane_bcast(rs, c);
+        static_for<0, 16>([&](auto cc) {
+          constexpr int C = decltype(cc)::value;
+          const double sc = row_bcast<C>(rs);
+          u[C] *= sc;
+          x[C] *= sc;
+        });
       } else {
         // the block already holds L_jj: only the identity rows are solved, x_c /= L_cc, x_k -= x_c L_kc
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double lcc = lane_bcast(v[c], c);
-          const double xc = v[c] / lcc;
-          if (idn) v[c] = xc;
-#pragma unroll
-          for (int k = c + 1; k < 16; ++k) {
-            const double u = __builtin_fma(-xc, lane_bcast(v[c], k), v[k]);   // L_kc from lane k
-            if (idn) v[k] = u;
-          }
-        }
+        static_for<0, 16>([&](auto cc) {
+          constexpr int C = decltype(cc)::value;
+          const double xc = x[C] / row_bcast<C>(u[C]);
+          x[C] = xc;
+          static_for<C + 1, 16>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            x[K] = __builtin_fma(-xc, row_bcast<K>(u[C]), x[K]);
+          });
+        });
       }
-      if (blk && FACTOR) {
+      if (lane < 16 && FACTOR) {
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-          if (c <= i) a[(c0 + i) * LSA + c0 + c] = v[c];
+          if (c <= i) a[(c0 + i) * LSA + c0 + c] = u[c];
       }
-      if (idn) {
+      if (lane >= 16 && lane < 32) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) wd[(jb * 16 + i) * LSW + c] = v[c];
+        for (int c = 0; c < 16; ++c) wd[(jb * 16 + i) * LSW + c] = x[c];
       }
     }
     __syncthreads();
