@@ -30,7 +30,7 @@ struct gpk_context {
   size_t serve_host_bytes = 0;
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
-  int gemm_small_tiles = 128;
+  int gemm_small_tiles = 1024;   // launches with fewer 128 x 128 tiles than this run on 64 x 64 tiles (GPK_GEMM_SMALL)
   int trtri_levels = 1;      // gpk_trtri: one batched launch per level for power-of-two tile counts (GPK_TRTRI_LEVELS=0: recursion)
   int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
@@ -41,7 +41,7 @@ struct gpk_context {
   // buffer's stride per problem, any other pointer is shared by all problems.
   struct BatchBuf { const char* base; long long stride; };
   int batch = 1;
-  std::vector<BatchBuf> bbufs;   // launches with fewer 128x128 tiles than this run on 64x64 tiles
+  std::vector<BatchBuf> bbufs;
 };
 
 #define GPK_CHECK_HIP(h, call)                                                          \
