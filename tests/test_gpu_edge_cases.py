@@ -158,3 +158,36 @@ def test_predict_during_refit_threads(csv_data):
         t.join(30)
     assert not errors, errors[:3]
     assert "new" in seen or "old" in seen
+
+
+@pytest.mark.parametrize("N,M", [(4961, 300), (8900, 1100)])
+def test_no_reads_of_unwritten_memory(N, M, monkeypatch):
+    """Every fresh device buffer is poisoned with NaN (GPK_DEBUG_FILL): a kernel that reads memory nobody wrote --
+    the part of a triangular operand beyond its zero band, an unwritten scratch tile -- turns the result into NaN
+    instead of passing by the luck of a zero-filled allocation.  Ragged tile counts (39 and 70 tiles: groups of the
+    tile walk run across bands and the last band is short) through factorisation, inverse factor, both alpha
+    solves and every variance path."""
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
+    monkeypatch.setenv("GPK_DEBUG_FILL", "nan")
+    rng = np.random.default_rng(N)
+    X = rng.standard_normal((N, 7)); Y = np.sin(X @ rng.standard_normal((7, 2))) + 0.1 * rng.standard_normal((N, 2))
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    Xq = rng.standard_normal((M, 7))
+    dev = DeviceGP(X, Y, get_backend(0))
+    dev.factorize(2.0, 1.0, 0.03)
+    dev.solve_alpha("chain")
+    a_chain = dev.alpha_host()
+    dev.solve_alpha("inverse")
+    a_inv = dev.alpha_host()
+    assert np.all(np.isfinite(a_chain)) and relerr(a_inv, a_chain) < 1e-9
+    logdet, quad = dev.lml_terms()
+    assert np.isfinite(logdet) and np.all(np.isfinite(quad))
+    v_solve = dev.predict_var_dev(Xq, 1.03, 0.0, "float64", "solve").cpu().numpy()
+    v_inv = dev.predict_var_dev(Xq, 1.03, 0.0, "float64", "inverse").cpu().numpy()
+    v32 = dev.predict_var_dev(Xq, 1.03, 0.0, "float32", "inverse").cpu().numpy()
+    vsp = dev.predict_var_dev(Xq, 1.03, 0.0, "float32", "inverse_split").cpu().numpy()
+    assert np.all(np.isfinite(v_solve)) and np.max(np.abs(v_inv - v_solve)) < 1e-10
+    assert np.max(np.abs(np.sqrt(v32) - np.sqrt(v_solve)) / np.sqrt(v_solve)) < 1e-3
+    assert np.max(np.abs(np.sqrt(vsp) - np.sqrt(v_solve)) / np.sqrt(v_solve)) < 1e-3
+    g = dev.lml_grad(0.03)
+    assert np.all(np.isfinite(g))

@@ -8,6 +8,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPK_DEBUG_FILL", "nan")   # poison fresh device buffers: reads of unwritten memory become NaN
 import numpy as np  # noqa: E402
 from oracle import gp_oracle as O  # noqa: E402
 from unmanned_aerial_vehicles_amd import BatchedARDGP, GaussianProcess, RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel  # noqa: E402

@@ -381,11 +381,17 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
       int band;
       place(t, tm, tn, band);
       if (p.k_super) {
+        // the union is taken over the part of the group that lies in this tile's own band: at most sr rows and
+        // 64 / sr columns, whatever the grid width -- a group that runs on into the next band must not widen the
+        // k-range to all columns (the zero band of a triangular operand is only GPK_ZERO_BAND_TILES wide)
         int r0, c0, b0, r1, c1, b1;
         place(st * 64, r0, c0, b0);
         place(min(st * 64 + 63, total - 1), r1, c1, b1);
-        rlo = b0 * sr; rhi = min(b1 * sr + sr - 1, p.ntm - 1);
-        if (b0 == b1) { clo = c0; chi = c1; } else { clo = 0; chi = p.ntn - 1; }
+        rlo = band * sr; rhi = min(band * sr + sr - 1, p.ntm - 1);
+        clo = band == b0 ? c0 : 0;
+        chi = band == b1 ? c1 : p.ntn - 1;
+        // (a short last band makes its groups wide: 64 / 3 columns for three leftover rows)
+        if ((chi - clo + 1) * TS > 8 * 128) clo = chi = tn;
       }
     }
     if (p.k_super && p.heavy_first) { const int a0 = p.ntm - 1 - rhi, a1 = p.ntm - 1 - rlo; rlo = a0; rhi = a1; }

@@ -13,6 +13,7 @@ Layout in HBM (row-major, Np = N rounded up to 128, identity in the padding):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -65,7 +66,10 @@ class Backend:
         self.check(self.lib.gpk_synchronize(self.h))
 
     def empty(self, shape, dtype):
-        return _torch().empty(shape, dtype=dtype, device=self.device)
+        t = _torch().empty(shape, dtype=dtype, device=self.device)
+        if os.environ.get("GPK_DEBUG_FILL"):      # debugging aid: poison fresh buffers (reads of unwritten memory show up as NaN)
+            t.fill_(float(os.environ["GPK_DEBUG_FILL"]) if t.is_floating_point() else 255)   # (bytes 0xFF: NaN as bf16 pairs)
+        return t
 
     def upload(self, a, dtype=None):
         torch = _torch()
