@@ -15,6 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# Every device buffer the package allocates during the tests starts out as NaN: a kernel that reads memory nobody
+# wrote fails the parity check instead of passing on a freshly zeroed allocation (device.Backend.empty).
+os.environ.setdefault("GPK_DEBUG_FILL", "nan")
 
 
 def pytest_configure(config):
