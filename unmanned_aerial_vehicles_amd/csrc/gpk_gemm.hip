@@ -381,13 +381,15 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
       int band;
       place(t, tm, tn, band);
       if (p.k_super) {
-        // the union is taken over the part of the group that lies in this tile's own band: at most sr rows and
-        // 64 / sr columns, whatever the grid width -- a group that runs on into the next band must not widen the
-        // k-range to all columns (the zero band of a triangular operand is only GPK_ZERO_BAND_TILES wide)
+        // Rows: the whole group, i.e. at most two bands of sr tile rows (what the launch-side gate admits), so that
+        // a group that runs on into the next band stays in lockstep.  Columns: only the group's part in this
+        // tile's own band -- at most 64 / sr columns -- never the full width between the two parts (the zero band
+        // of a triangular operand is only GPK_ZERO_BAND_TILES wide).
         int r0, c0, b0, r1, c1, b1;
         place(st * 64, r0, c0, b0);
         place(min(st * 64 + 63, total - 1), r1, c1, b1);
-        rlo = band * sr; rhi = min(band * sr + sr - 1, p.ntm - 1);
+        if (b1 - b0 <= 1) { rlo = b0 * sr; rhi = min(b1 * sr + sr - 1, p.ntm - 1); }
+        else { rlo = band * sr; rhi = min(band * sr + sr - 1, p.ntm - 1); }
         clo = band == b0 ? c0 : 0;
         chi = band == b1 ? c1 : p.ntn - 1;
         // (a short last band makes its groups wide: 64 / 3 columns for three leftover rows)
