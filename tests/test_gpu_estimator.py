@@ -40,7 +40,8 @@ def test_fixed_theta_vs_sklearn(csv_data, ka, name, D, cols, ls, noise):
     assert np.array_equal(mean_only, mean)
     g.var_method = "solve"                      # the reference's solve_triangular form
     mean_s, std_s = g.predict(Xq, return_std=True)
-    assert np.array_equal(mean_s, mean) and relerr(std_s, ka[f"{name}_std"]) < TOL
+    # (64 rows: 'auto' takes the small-batch kernels, 'solve' the general ones: same mean to round-off)
+    assert relerr(mean_s, mean) < 1e-13 and relerr(std_s, ka[f"{name}_std"]) < TOL
     g.var_method = "auto"
     if name != "ka1":
         lml, grad = g.log_marginal_likelihood(g.kernel_.theta, eval_gradient=True)
@@ -328,7 +329,7 @@ def test_small_batch_kernels_vs_oracle():
         kern = RBF(ls) + WhiteKernel(0.05) if sf2 == 1.0 else ConstantKernel(sf2) * RBF(ls) + WhiteKernel(0.05)
         gp = GaussianProcessRegressor(kernel=kern, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, Y)
         st = O.fit_fixed(X, Y, ls, sf2, 0.05, 1e-6, True)
-        for M in (1, 2, 15, 16, 17, 25, 32):
+        for M in (1, 2, 15, 16, 17, 25, 32, 33, 50, 64):          # (33..64: two passes of the small-batch kernels)
             Xq = rng.standard_normal((M, D)) * 1.2
             assert gp._dev.host_path_ok(M, True)
             for _ in range(2):

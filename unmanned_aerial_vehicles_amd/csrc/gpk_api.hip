@@ -182,7 +182,8 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
   GPK_REQUIRE(h, !var_host || (W && Np == gpk_padded(N) && ldw >= Np), "predict_host: variance needs the inverse factor");
   GPK_REQUIRE(h, h->batch == 1, "predict_host: not available in batched mode");
   const int64_t Mp = gpk_padded(M);
-  const bool small = h->small_path && gpk_small_ok(gpk_padded(N), D, P, M);
+  // up to 32 queries: the two small-batch launches; 33..64: the same twice (4 launches instead of the general chain's 7)
+  const bool small = h->small_path && M <= 2 * GPK_SMALL_MAX_M && gpk_small_ok(gpk_padded(N), D, P, M < GPK_SMALL_MAX_M ? M : GPK_SMALL_MAX_M);
   // pinned host block [Xq | pad][mean | var | pad]; device block [Xq | pad][work: the K* panel of the variance GEMM,
   // or the small-batch kernels' K* and shares]
   const size_t nq = ((size_t)M * D + 15) & ~(size_t)15, nm = (size_t)M * P, nv = (size_t)M;
@@ -202,8 +203,11 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
   double* dwork = dq + nq;
   memcpy(hq, Xq_host, (size_t)M * D * sizeof(double));
   if (small) {
-    GPK_TRY(gpk_small_predict(h, 1, &X, &alpha, N, D, P, ls, &sf2, y_mean, y_std, &W, gpk_padded(N), ldw, &kss, floor_, hq, M,
-                              dwork, hout, var_host ? hout + nm : nullptr));
+    for (int64_t m0 = 0; m0 < M; m0 += GPK_SMALL_MAX_M) {
+      const int64_t mc = M - m0 < GPK_SMALL_MAX_M ? M - m0 : GPK_SMALL_MAX_M;
+      GPK_TRY(gpk_small_predict(h, 1, &X, &alpha, N, D, P, ls, &sf2, y_mean, y_std, &W, gpk_padded(N), ldw, &kss, floor_,
+                                hq + m0 * D, mc, dwork, hout + m0 * P, var_host ? hout + nm + m0 : nullptr));
+    }
   } else {
     GPK_CHECK_HIP(h, hipMemcpyAsync(dq, hq, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
     GPK_TRY(gpk_predict_mean(h, GPK_F64, X, alpha, N, D, P, ls, sf2, y_mean, y_std, dq, M, hout));
