@@ -217,7 +217,7 @@ int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, co
  * end of the longest row so that its 64 workgroups stay in lockstep and share operand panels through L2 -
  * W must therefore be ZERO above the diagonal for 16 tiles (2048 columns) from each row's diagonal tile
  * rightwards, which gpk_trtri and gpk_tril_to_f32 guarantee).  W, X, Xq of `dtype`; work: dev scratch
- * of Mp * Np elements of `dtype`; var: dev double[Mp].
+ * of Mp * Np elements of `dtype`; var: dev double[M] (only M entries are written).
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485),
  * with solve_triangular(L, K*^T) evaluated as (L^-1) K*^T.                                          */
 int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,

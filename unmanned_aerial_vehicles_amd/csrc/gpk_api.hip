@@ -146,8 +146,7 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
   g.C = partial;
   GPK_TRY(gpk_gemm(h, dtype, g));
-  GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntm, Mp, var));
-  return gpk_var_finalize(h, var, M, kss, floor_, var);
+  return gpk_colsum_finalize(h, (const double*)partial, ntm, Mp, M, kss, floor_, var);
 }
 
 // ---- one-call serving for the control loop: host queries in, host mean / variance out ------------------

@@ -565,6 +565,15 @@ __global__ void colsum_reduce_kernel(const double* __restrict__ partial, int S, 
   for (int k = 0; k < S; ++k) s += partial[(long long)k * Mp + m];
   out[m] = s;
 }
+// sum of the S partial rows and the clipped variance in one launch: var[m] = max(kss - sum_k partial[k][m], floor)
+__global__ void colsum_finalize_kernel(const double* __restrict__ partial, int S, long long Mp, long long M, double kss,
+                                       double floor_, double* __restrict__ var) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int k = 0; k < S; ++k) s += partial[(long long)k * Mp + m];
+  var[m] = fmax(kss - s, floor_);
+}
 __global__ void var_finalize_kernel(const double* ss, long long M, double kss, double floor_, double* var) {
   const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -784,6 +793,13 @@ extern "C" int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, 
   return GPK_OK;
 }
 
+int gpk_colsum_finalize(gpk_handle h, const double* partial, int S, int64_t Mp, int64_t M, double kss, double floor_,
+                        double* var) {
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, partial, S,
+                     (long long)Mp, (long long)M, kss, floor_, var);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out) {
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, h->stream, partial, S,
                      (long long)Mp, out);

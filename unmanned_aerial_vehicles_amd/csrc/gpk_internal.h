@@ -145,3 +145,5 @@ int gpk_small_predict(gpk_handle h, int B, const double* const* X, const double*
 
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out);
+int gpk_colsum_finalize(gpk_handle h, const double* partial, int S, int64_t Mp, int64_t M, double kss, double floor_,
+                        double* var);   // both of the above in one launch (entries M..Mp of var are left alone)

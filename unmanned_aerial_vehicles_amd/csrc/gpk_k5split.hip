@@ -356,6 +356,5 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
   else hipLaunchKernelGGL(k5_split_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
-  GPK_TRY(gpk_colsum_reduce(h, (const double*)partial, ntmT, Mp, var));
-  return gpk_var_finalize(h, var, M, kss, floor_, var);
+  return gpk_colsum_finalize(h, (const double*)partial, ntmT, Mp, M, kss, floor_, var);
 }
