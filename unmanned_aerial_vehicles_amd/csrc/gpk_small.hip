@@ -295,6 +295,7 @@ int gpk_small_predict(gpk_handle h, int B, const double* const* X, const double*
   SmallK k{};
   for (int b = 0; b < B; ++b) {
     GPK_REQUIRE(h, X[b] && alpha[b] && (!var_out || W[b]), "small predict: null model pointer");
+    GPK_REQUIRE(h, !var_out || ((uintptr_t)W[b] % 16) == 0, "small predict: the inverse factor must be 16-byte aligned");
     k.X[b] = X[b]; k.alpha[b] = alpha[b]; k.W[b] = var_out ? W[b] : nullptr;
     for (int d = 0; d < 16; ++d) k.ls[b][d] = 1.0;
     for (int d = 0; d < D; ++d) {
