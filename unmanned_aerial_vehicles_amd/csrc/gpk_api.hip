@@ -33,6 +33,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_TRSM256")) h->trsm256 = atoi(e);
   if (const char* e = getenv("GPK_TRTRI_LEVELS")) h->trtri_levels = atoi(e);
   if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
+  if (getenv("GPK_DEBUG_FILL")) h->debug_fill = 1;
   *out = h;
   return GPK_OK;
 }
@@ -104,6 +105,8 @@ int gpk_scratch(gpk_handle h, size_t bytes, void** out) {
     GPK_CHECK_HIP(h, hipMalloc(&h->scratch, want));
     h->scratch_bytes = want;
   }
+  // debugging aid (the tests run with it): whoever asked for scratch must write it before reading it
+  if (h->debug_fill && bytes > 0) GPK_CHECK_HIP(h, hipMemsetAsync(h->scratch, 0xFF, bytes, h->stream));
   *out = h->scratch;
   return GPK_OK;
 }
@@ -200,6 +203,7 @@ extern "C" int gpk_predict_host(gpk_handle h, const double* X, const double* alp
   double* hout = hq + nq;                      // [mean | var]
   double* dq = (double*)h->serve_dev;
   double* dwork = dq + nq;
+  if (h->debug_fill && work_need > 0) GPK_CHECK_HIP(h, hipMemsetAsync(dwork, 0xFF, work_need * sizeof(double), h->stream));
   memcpy(hq, Xq_host, (size_t)M * D * sizeof(double));
   if (small) {
     for (int64_t m0 = 0; m0 < M; m0 += GPK_SMALL_MAX_M) {

@@ -35,6 +35,7 @@ struct gpk_context {
   int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
+  int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // batched mode (gpk_batch_begin .. gpk_batch_end): `batch` same-shaped problems per call.  Pointers passed
   // to the entry points address problem 0; a pointer that falls inside a registered buffer advances by that
