@@ -191,3 +191,33 @@ def test_no_reads_of_unwritten_memory(N, M, monkeypatch):
     assert np.max(np.abs(np.sqrt(vsp) - np.sqrt(v_solve)) / np.sqrt(v_solve)) < 1e-3
     g = dev.lml_grad(0.03)
     assert np.all(np.isfinite(g))
+
+
+def test_fast_paths_match_their_plain_forms(monkeypatch):
+    """The round's shortcuts against the forms they replace, on a second handle with the switches off (the switches
+    are read when a handle is created): fused 256-wide solve base vs three launches, level-by-level inverse vs the
+    recursion, 64-tile launches vs 128-tile ones, small-batch serving kernels vs the general chain."""
+    from unmanned_aerial_vehicles_amd.device import Backend, DeviceGP, get_backend
+    fast = get_backend(0)
+    for k, v in (("GPK_TRSM256", "0"), ("GPK_TRTRI_LEVELS", "0"), ("GPK_GEMM_SMALL", "128"), ("GPK_SMALL_PATH", "0")):
+        monkeypatch.setenv(k, v)
+    plain = Backend(0)
+    for k in ("GPK_TRSM256", "GPK_TRTRI_LEVELS", "GPK_GEMM_SMALL", "GPK_SMALL_PATH"):
+        monkeypatch.delenv(k)
+    rng = np.random.default_rng(5)
+    for N in (1000, 2048, 4096, 4961):
+        X = rng.standard_normal((N, 8)); Y = np.sin(X @ rng.standard_normal((8, 3))) + 0.1 * rng.standard_normal((N, 3))
+        Y = (Y - Y.mean(0)) / Y.std(0)
+        out = []
+        for be in (fast, plain):
+            dev = DeviceGP(X, Y, be)
+            dev.factorize(1.8, 1.0, 0.05)
+            L = np.tril(dev.K.cpu().numpy())
+            W = np.tril(dev.inverse_factor(False).cpu().numpy())
+            dev.solve_alpha()
+            q = rng.standard_normal((25, 8)) if not out else out[0][3]
+            mean, var = dev.predict_host(q, np.zeros(3), np.ones(3), 1.05, 0.0)
+            out.append((L, W, dev.alpha_host(), q, mean, var))
+        (L1, W1, a1, _, m1, v1), (L2, W2, a2, _, m2, v2) = out
+        assert relerr(L1, L2) < 1e-13 and relerr(W1, W2) < 1e-11 and relerr(a1, a2) < 1e-10, N
+        assert relerr(m1, m2) < 1e-11 and relerr(v1, v2) < 1e-9, N
