@@ -42,8 +42,9 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("no oracle", ""), f"{fn} mentions the oracle"
-            assert "sklearn." not in src.replace("sklearn.utils.check_random_state", "").replace(
-                "sklearn.gaussian_process", "").replace("`sklearn/", "") or True
+            # scikit-learn is never imported by the product (docstrings cite `sklearn/...:line` and name
+            # `sklearn.utils.check_random_state`; neither is an import)
+            assert not re.search(r"^\s*(from|import)\s+sklearn\b", src, flags=re.M), f"{fn} imports scikit-learn"
 
 
 def test_kernel_spec_theta_bounds_repr():
@@ -97,7 +98,9 @@ def test_csv_pipeline(tmp_path, csv_data):
     Yb[9] = [5, 0, 0, 0, 0, 0]
     Yb[11] = [4.999, 0, 0, 0, 0, 0]
     Xf, Yf = filter_rows(Xb, Yb)
-    assert len(Xf) == 47 and np.array_equal(Yf[9], Yb[11] if False else Yf[9])
+    keep = [i for i in range(50) if i not in (3, 7, 9)]                         # row 11 (norm 4.999 < 5) stays
+    assert len(Xf) == 47 and np.array_equal(Xf, Xb[keep]) and np.array_equal(Yf, Yb[keep])
+    assert np.array_equal(Yf[keep.index(11)], [4.999, 0, 0, 0, 0, 0])
     from unmanned_aerial_vehicles_amd.data import save_dataset_csv
     save_dataset_csv(str(tmp_path / "a" / "set0.csv"), Xb, Yb)
     open(tmp_path / "a" / "set0_metrics.csv", "w").write("component,mse\n")
@@ -127,6 +130,84 @@ def test_add_training_data_filters():
     assert not gp.is_trained
     st = gp.get_stats()
     assert st["data_points"] == 1 and st["training_iterations"] == 0 and st["is_trained"] is False
+
+
+def test_csv_loader_vs_reference_fixture(tmp_path, loader_ref):
+    """(f)2: the rows `load_csv_data_simple` (train_gp_offline.py:22-76) kept from a CSV with injected NaN / inf /
+    ||y|| >= 5 rows, frozen by tests/golden/make_golden_r2.py, against this package's loader on the same file."""
+    from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP
+    from unmanned_aerial_vehicles_amd.data import load_csv_rows
+    rows, header = loader_ref["csv_rows"], str(loader_ref["csv_header"])
+    p = str(tmp_path / "inj.csv")
+    np.savetxt(p, rows, delimiter=",", header=header, comments="")
+    gp = SimpleQuadrotorGP(max_data_points=10000)
+    assert load_csv_rows(gp, p) == int(loader_ref["csv_kept_count"]) == 112
+    # same rows in the same order.  Values: the reference parses with pandas' default (fast, not round-trip) float
+    # converter and is off by up to 2 ulp from the decimal text on a third of the entries; this loader parses
+    # exactly - it reproduces the array the CSV was written from bit for bit - so the two agree to 4 ulp
+    keep = [i for i in range(120) if i not in (3, 10, 25, 40, 55, 56, 80, 81)]
+    assert np.array_equal(np.array(gp.X_train), rows[keep, :10]) and np.array_equal(np.array(gp.Y_train), rows[keep, 10:])
+    assert np.allclose(np.array(gp.X_train), loader_ref["csv_kept_X"], rtol=4 * 2.3e-16, atol=0)
+    assert np.allclose(np.array(gp.Y_train), loader_ref["csv_kept_Y"], rtol=4 * 2.3e-16, atol=0)
+    # columns are located by name: a permuted file gives the same training set
+    perm = loader_ref["csv_perm"]
+    p2 = str(tmp_path / "perm.csv")
+    np.savetxt(p2, rows[:, perm], delimiter=",", header=",".join(np.array(header.split(","))[perm]), comments="")
+    gp2 = SimpleQuadrotorGP(max_data_points=10000)
+    assert load_csv_rows(gp2, p2) == int(loader_ref["csv_perm_kept_count"])
+    assert np.allclose(np.array(gp2.X_train), loader_ref["csv_perm_kept_X"], rtol=4 * 2.3e-16, atol=0)
+    assert np.array_equal(np.array(gp2.X_train), np.array(gp.X_train))
+    # a missing column: nothing is loaded (the reference prints and returns 0)
+    p3 = str(tmp_path / "missing.csv")
+    np.savetxt(p3, rows[:, :15], delimiter=",", header=",".join(header.split(",")[:15]), comments="")
+    gp3 = SimpleQuadrotorGP(max_data_points=10000)
+    assert load_csv_rows(gp3, p3) == int(loader_ref["csv_missing_kept_count"]) == 0 and len(gp3.X_train) == 0
+
+
+def test_add_training_data_vs_reference_fixture(loader_ref):
+    """(f)2: `SimpleQuadrotorGP.add_training_data` (simple_gp.py:118-140) on 60 transitions with |v| > 5, |a| > 3,
+    ||residual|| > 2 and exactly-at-threshold cases: kept indices and stored rows of the reference class."""
+    from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP
+    S, U, Nx, dt = (loader_ref[k] for k in ("atd_states", "atd_controls", "atd_next", "atd_dt"))
+    gp = SimpleQuadrotorGP(max_data_points=10000)
+    kept = []
+    for i in range(len(S)):
+        before = len(gp.X_train)
+        gp.add_training_data(S[i], U[i], Nx[i], dt=float(dt[i]))
+        if len(gp.X_train) > before:
+            kept.append(i)
+    assert kept == list(loader_ref["atd_kept"]) and sorted(set(range(60)) - set(kept)) == [5, 9, 20]
+    assert np.array_equal(np.array(gp.X_train), loader_ref["atd_X"])
+    assert np.array_equal(np.array(gp.Y_train), loader_ref["atd_Y"])          # residuals bit for bit
+    small = SimpleQuadrotorGP(max_data_points=16)
+    for i in range(len(S)):
+        small.add_training_data(S[i], U[i], Nx[i], dt=float(dt[i]))
+    assert np.array_equal(np.array(small.X_train), loader_ref["atd_small_X"])  # deque eviction (simple_gp.py:31-32)
+
+
+def test_pretrained_gp_never_raises(tmp_path, trainer_ref):
+    """`PreTrainedGP` on a pickle whose models are foreign objects (what the reference's gp_trainer.py writes):
+    loading and predicting never raise; without a GPU every component falls back to (0, 1e6)
+    (pretrained_gp.py:52-98).  The numeric parity of the same pickle is a GPU test."""
+    import pickle
+    from unmanned_aerial_vehicles_amd.trainer import PreTrainedGP, _as_scaler
+    from conftest import reference_pickle_dict
+    d = reference_pickle_dict(trainer_ref)
+    path = str(tmp_path / "ref_model.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(d, f)
+    pre = PreTrainedGP(path)
+    assert pre.is_loaded and sorted(pre.gp_models) == sorted(str(n) for n in trainer_ref["names"])
+    sc = _as_scaler(d["scalers_y"]["vz_residual"])
+    assert np.array_equal(sc.scale_, trainer_ref["vz_residual_sy_scale"])
+    import torch
+    if not torch.cuda.is_available():
+        m, s = pre.predict_residual(trainer_ref["Xq"][0, :6], trainer_ref["Xq"][0, 6:])
+        assert np.array_equal(m, np.zeros(6)) and np.array_equal(s, np.full(6, 1e6))
+    missing = PreTrainedGP(str(tmp_path / "nope.pkl"))
+    assert not missing.is_loaded
+    m, s = missing.predict_residual(np.zeros(6), np.zeros(4))
+    assert np.array_equal(m, np.zeros(6)) and np.array_equal(s, np.full(6, 1e6))
 
 
 def test_evaluation_table_with_oracle_predictions(csv_data, eval_table):

@@ -146,10 +146,7 @@ class BatchedARDGP:
             return self._lml_fused(thetas, eval_gradient)
 
         def one(b):
-            g = self.models[b]
-            out = g._lml_on_device(thetas[b], eval_gradient)
-            g._refactor()
-            return out
+            return self.models[b].log_marginal_likelihood(thetas[b], eval_gradient)
 
         res = self._map(one, len(self.models))
         if not eval_gradient:
@@ -168,13 +165,20 @@ class BatchedARDGP:
             Np = m0._dev.Np
             tsz = (Np // 2 + 128) ** 2
             f64 = torch.float64
+            # per-model rows of Yn / alpha are registered as batch buffers: gpk_batch_buffer wants strides that are
+            # multiples of 16 bytes, so the rows are N rounded up to even long (an odd N - e.g. 241 of 302 samples
+            # after the 80/20 split - otherwise fails with GPK_BAD_ARG)
+            Ne = N + (N & 1)
+            Yn = torch.zeros((B, Ne), dtype=f64, device=be.device)
+            for b, m in enumerate(self.models):
+                Yn[b, :N].copy_(m._dev.Yn[:, 0])
             self._fs = {
-                "be": be, "B": B, "N": N, "D": D, "Np": Np, "tsz": tsz,
+                "be": be, "B": B, "N": N, "Ne": Ne, "D": D, "Np": Np, "tsz": tsz,
                 "X": m0._dev.X.to(be.device),
-                "Yn": torch.stack([m._dev.Yn[:, 0].to(be.device) for m in self.models]).contiguous(),   # (B, N)
+                "Yn": Yn,                                                                              # (B, Ne)
                 "K": be.empty((B, Np, Np), f64), "winv": be.empty((B, Np, 128), f64),
                 "W": be.empty((B, Np, Np), f64), "Kinv": be.empty((B, Np, Np), f64),
-                "T": be.empty((B, tsz), f64), "alpha": be.empty((B, N), f64),
+                "T": be.empty((B, tsz), f64), "alpha": be.empty((B, Ne), f64),
             }
         return self._fs
 
@@ -194,7 +198,8 @@ class BatchedARDGP:
             be.check(lib.gpk_batch_begin(be.h, B))
             try:
                 for name, row_bytes in (("K", Np * Np * 8), ("winv", Np * 128 * 8), ("W", Np * Np * 8),
-                                        ("Kinv", Np * Np * 8), ("T", fs["tsz"] * 8), ("Yn", N * 8), ("alpha", N * 8)):
+                                        ("Kinv", Np * Np * 8), ("T", fs["tsz"] * 8), ("Yn", fs["Ne"] * 8),
+                                        ("alpha", fs["Ne"] * 8)):
                     be.check(lib.gpk_batch_buffer(be.h, p(fs[name]), row_bytes))
                 rc = lib.gpk_potrf(be.h, p(fs["K"]), Np, Np, p(fs["winv"]), info)          # K2, B problems
                 if rc not in (_lib.GPK_OK, _lib.GPK_NOT_PD):

@@ -142,7 +142,7 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   g.ke0 = GPK_TILE;
   g.ke_row = GPK_TILE;
   g.epilogue = 1;
-  g.k_super = h->k5_super;   // W is zero right of the diagonal for 8 tiles (gpk_trtri, gpk_tril_to_f32)
+  g.k_super = h->k5_super;   // W is zero right of the diagonal for GPK_ZERO_BAND_TILES - 1 tiles (gpk_trtri, gpk_tril_to_f32)
   g.heavy_first = 1;   // row tile tm costs (tm + 1) k-blocks: start the long ones first
   const int ntm = (int)(Np / gpk_gemm_tile(h, g));       // one partial row per tile row of the launch
   void* partial = nullptr;

@@ -516,7 +516,7 @@ int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const doubl
   // T (n2 x n1) = L21 * W11   (W11 lower: k >= column tile start)
   GemmArgs g = gemm_args(L + n1 * ldl, ldl, 0, W, ldw, 1, T, ldt, (int)n2, (int)n1, (int)n1, 1.0, 0.0);
   g.kb_col = NB;
-  g.k_super = 1;           // W is zero right of the diagonal for 8 tiles (zero_band_kernel)
+  g.k_super = 1;           // W is zero right of the diagonal for GPK_ZERO_BAND_TILES - 1 tiles (zero_band_kernel)
   GPK_TRY(gpk_gemm(h, GPK_F64, g));
   // W21 = -W22 * T          (W22 lower: k < row tile end)
   GemmArgs g2 = gemm_args(W + n1 * ldw + n1, ldw, 0, T, ldt, 1, W + n1 * ldw, ldw, (int)n2, (int)n1, (int)n2, -1.0, 0.0);
@@ -708,7 +708,7 @@ extern "C" int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, d
   GemmArgs g = gemm_args(W, ldw, 1, W, ldw, 1, Kinv, ldk, (int)Np, (int)Np, (int)Np, 1.0, 0.0);
   g.lower_only = 1;
   g.kb_row = NB;
-  g.k_super = 1;           // W (from gpk_trtri) is zero above the diagonal for 8 tiles
+  g.k_super = 1;           // W (from gpk_trtri) is zero right of the diagonal for GPK_ZERO_BAND_TILES - 1 tiles
   return gpk_gemm(h, GPK_F64, g);
 }
 
@@ -717,10 +717,12 @@ extern "C" int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl,
   if (!h) return GPK_BAD_ARG;
   GPK_REQUIRE(h, L && winv && Kinv && work, "potri: null pointer");
   GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldl >= Np && ldk >= Np, "potri: Np must be a multiple of 128");
-  // work holds W = L^-1 (Np x Np; only lower and diagonal tiles are written or read);
-  // Kinv doubles as the recursion scratch T before it is written
+  // work holds W = L^-1 (Np x Np: lower and diagonal tiles plus the band of zeros right of the diagonal that the
+  // lockstep launches of gpk_trtri / gpk_wtw read - gpk_trtri writes both, `work` may hold anything on entry);
+  // Kinv doubles as the recursion scratch ((Np/2 + 128)^2 <= Np^2 doubles for Np >= 256; unused at Np = 128)
+  // before it is written
   double* W = work;
-  GPK_TRY(trtri_rec(h, L, ldl, Np, winv, W, Np, Kinv, ldk));
+  GPK_TRY(gpk_trtri(h, L, Np, ldl, winv, W, Np, Kinv));
   return gpk_wtw(h, W, Np, Np, Kinv, ldk);
 }
 

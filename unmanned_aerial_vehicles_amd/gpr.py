@@ -151,22 +151,24 @@ class GaussianProcessRegressor:
         raise ValueError(f"Unknown optimizer {self.optimizer}.")
 
     # ------------------------------------------------------------------ LML
-    def _lml_on_device(self, theta, eval_gradient):
-        """One evaluation of `_gpr.py:537-652` on the GPU: K1, K2, K3, K6a (+ K^-1 and K6b)."""
+    def _lml_on_device(self, theta, eval_gradient, dev=None):
+        """One evaluation of `_gpr.py:537-652` on the GPU: K1, K2, K3, K6a (+ K^-1 and K6b).  Works on `dev`
+        (default: the estimator's own device model, whose factor it overwrites - what `fit` wants)."""
+        dev = dev if dev is not None else self._dev
         kern = self.kernel_.clone_with_theta(theta)
         comp = kern.components()
         D = self.n_features_in_
         try:
-            self._dev.factorize(comp.ls_vector(D), comp.sf2, (comp.noise or 0.0) + float(self.alpha))
+            dev.factorize(comp.ls_vector(D), comp.sf2, (comp.noise or 0.0) + float(self.alpha))
         except NotPositiveDefinite:
             return (-np.inf, np.zeros_like(theta)) if eval_gradient else -np.inf
-        self._dev.solve_alpha()
-        logdet_half, quad = self._dev.lml_terms()
-        N, P = self._dev.N, self._dev.P
+        dev.solve_alpha()
+        logdet_half, quad = dev.lml_terms()
+        N = dev.N
         lml = float(np.sum(-0.5 * quad - logdet_half - 0.5 * N * LOG_2PI))
         if not eval_gradient:
             return lml
-        g = self._dev.lml_grad(comp.noise or 0.0)
+        g = dev.lml_grad(comp.noise or 0.0)
         return lml, comp.map_gradient(g, D)
 
     def log_marginal_likelihood(self, theta=None, eval_gradient=False, clone_kernel=True):
@@ -174,14 +176,23 @@ class GaussianProcessRegressor:
             if eval_gradient:
                 raise ValueError("Gradient can only be evaluated for theta!=None")
             return self.log_marginal_likelihood_value_
-        self._ensure_device()
+        if not hasattr(self, "X_train_"):
+            raise RuntimeError("This GaussianProcessRegressor instance is not fitted yet.")
         theta = np.asarray(theta, dtype=np.float64)
-        out = self._lml_on_device(theta, eval_gradient)
-        # restore the fitted factorisation (the evaluation overwrote the factor in HBM)
-        self._refactor()
+        # Non-mutating, as in scikit-learn (_gpr.py:537-652 works on fresh arrays): the trial theta is factorised
+        # in a scratch device model, so the fitted factor in HBM - which a predict() on another thread may be
+        # reading - is never touched.  The scratch (a second N x N matrix) is kept for the next evaluation;
+        # `release_lml_scratch()` frees it.
+        scratch = getattr(self, "_lml_dev", None)
+        if scratch is None or scratch.N != self.X_train_.shape[0]:
+            scratch = self._lml_dev = DeviceGP(self.X_train_, self._yn, get_backend(self.device))
+        out = self._lml_on_device(theta, eval_gradient, scratch)
         if not clone_kernel:
             self.kernel_.theta = theta
         return out
+
+    def release_lml_scratch(self):
+        self._lml_dev = None
 
     # ------------------------------------------------------------------ predict
     def predict(self, X, return_std=False, return_cov=False):
@@ -269,6 +280,7 @@ class GaussianProcessRegressor:
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_dev"] = None
+        st.pop("_lml_dev", None)
         if not isinstance(st.get("device"), (int, type(None))):     # a private Backend (handle + stream): keep its index
             st["device"] = getattr(st["device"], "device_index", None)
         st.pop("_rng", None)

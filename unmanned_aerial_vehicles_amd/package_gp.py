@@ -139,8 +139,11 @@ class GaussianProcess:
         if len(self.X_train) < 2 or self.L is None:
             return -np.inf
         try:
-            dev = self._model[0]
-            logdet_half, quad = dev.lml_terms()
+            with self._swap:          # a refit on another thread replaces the snapshot; never read it half-swapped
+                model = self._model
+            if model is None:
+                return -np.inf
+            logdet_half, quad = model[0].lml_terms()
             n = len(self.X_train)
             return float(-0.5 * (2.0 * logdet_half + quad.sum() + n * self.output_dim * LOG_2PI))
         except Exception as e:  # noqa: BLE001
@@ -171,7 +174,9 @@ class GaussianProcess:
                 return (1e6, np.zeros(3)) if use_gradient else 1e6
             if not use_gradient:
                 return float(nll)
-            g = self._model[0].lml_grad(noise)            # d LML / d log [ls_d..., noise, sf2]
+            with self._swap:
+                model = self._model
+            g = model[0].lml_grad(noise)                  # d LML / d log [ls_d..., noise, sf2]
             return float(nll), -np.array([np.sum(g[:D]), g[D + 1], g[D]])
 
         x0 = np.log([self.kernel.length_scale, self.kernel.signal_variance, self.noise_variance])

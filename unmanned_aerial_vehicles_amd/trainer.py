@@ -43,6 +43,17 @@ class StandardScaler:
         return np.asarray(A, dtype=np.float64) * self.scale_ + self.mean_
 
 
+def _as_scaler(obj):
+    """This package's `StandardScaler` from any object carrying `mean_` and `scale_` (e.g. the scikit-learn
+    scalers inside a pickle written by the reference's `gp_trainer.py:214-221`)."""
+    if isinstance(obj, StandardScaler):
+        return obj
+    s = StandardScaler()
+    s.mean_ = np.asarray(obj.mean_, dtype=np.float64).copy()
+    s.scale_ = np.asarray(obj.scale_, dtype=np.float64).copy()
+    return s
+
+
 def train_test_split(X, y, test_size=0.2, random_state=42):
     """Shuffled split: permutation from RandomState(seed); the first ceil(test_size * n) indices are
     the test set, the rest the training set (the ShuffleSplit rule the reference relies on)."""
@@ -130,8 +141,12 @@ class GPTrainer:
     def load_models(self, model_path):
         with open(model_path, "rb") as f:
             d = pickle.load(f)
-        self.gp_models, self.scalers_X = d["gp_models"], d["scalers_X"]
-        self.scalers_y, self.training_stats = d["scalers_y"], d["training_stats"]
+        self.gp_models = {n: (m if isinstance(m, GaussianProcessRegressor)
+                              else GaussianProcessRegressor.from_sklearn(m, device=self.device))
+                          for n, m in d["gp_models"].items()}
+        self.scalers_X = {n: _as_scaler(v) for n, v in d["scalers_X"].items()}
+        self.scalers_y = {n: _as_scaler(v) for n, v in d["scalers_y"].items()}
+        self.training_stats = d["training_stats"]
 
 
 class PreTrainedGP:
@@ -148,39 +163,70 @@ class PreTrainedGP:
         try:
             with open(self.model_path, "rb") as f:
                 d = pickle.load(f)
-            self.gp_models, self.scalers_X = d["gp_models"], d["scalers_X"]
-            self.scalers_y, self.training_stats = d["scalers_y"], d["training_stats"]
-            self.is_loaded = True
-            return True
+            return self.load_dict(d)
         except Exception as e:  # noqa: BLE001
             print(f"Failed to load GP models: {e}")
             return False
 
+    def load_dict(self, d, device=None):
+        """Install the content of a model file.  The file may have been written by this package's `GPTrainer` or
+        by the reference's (`src/px4/gp_trainer.py:214-221`: scikit-learn regressors and scikit-learn
+        `StandardScaler`s): foreign regressors are ingested with `GaussianProcessRegressor.from_sklearn`
+        (X_train_, alpha_, L_, kernel_ and the target normalisation taken as they are), and any object carrying
+        `mean_` / `scale_` serves as a scaler.  A component that cannot be converted is dropped (its prediction is
+        then the reference's (0, 1e6) fallback, `pretrained_gp.py:93-96`)."""
+        models, sxs, sys_ = {}, {}, {}
+        for name, m in d["gp_models"].items():
+            try:
+                if not isinstance(m, GaussianProcessRegressor):
+                    m = GaussianProcessRegressor.from_sklearn(m, device=device)
+                models[name] = m
+                sxs[name] = _as_scaler(d["scalers_X"][name])
+                sys_[name] = _as_scaler(d["scalers_y"][name])
+            except Exception as e:  # noqa: BLE001
+                print(f"GP model {name} could not be loaded: {e}")
+                models.pop(name, None)
+        self.gp_models, self.scalers_X, self.scalers_y = models, sxs, sys_
+        self.training_stats = d.get("training_stats", {})
+        self._fused_bg = None
+        self.is_loaded = True
+        return True
+
     def predict_residual(self, state, control):
-        """One query -> (mean (6,), std (6,)); missing / failing components -> (0, 1e6)."""
-        mean, std = self.predict_residual_batch(
-            np.concatenate([np.asarray(state, float)[:6], np.asarray(control, float)[:4]]).reshape(1, -1))
-        return mean[0], std[0]
+        """One query -> (mean (6,), std (6,)); missing / failing components -> (0, 1e6).  Never raises
+        (`pretrained_gp.py:52-98`: the control loop calls this every step)."""
+        try:
+            mean, std = self.predict_residual_batch(
+                np.concatenate([np.asarray(state, float)[:6], np.asarray(control, float)[:4]]).reshape(1, -1))
+            return mean[0], std[0]
+        except Exception as e:  # noqa: BLE001
+            print(f"GP prediction failed: {e}")
+            return np.zeros(6), np.ones(6) * 1e6
 
     def _fused(self):
         """All loaded models share the input scaler and training inputs (they do when written by `GPTrainer`):
         evaluate their means with one fused launch."""
         if getattr(self, "_fused_bg", None) is None:
             self._fused_bg = False
-            names = [n for n in OUTPUT_NAMES if n in self.gp_models]
-            if 2 <= len(names) <= 8:
-                sx0 = self.scalers_X[names[0]]
-                m0 = self.gp_models[names[0]]
-                same = all(np.array_equal(self.scalers_X[n].mean_, sx0.mean_) and
-                           np.array_equal(self.scalers_X[n].scale_, sx0.scale_) and
-                           getattr(self.gp_models[n], "X_train_", np.empty(0)).shape == m0.X_train_.shape and
-                           np.array_equal(self.gp_models[n].X_train_, m0.X_train_) and
-                           self.gp_models[n]._yn.shape[1] == 1 for n in names)
-                if same:
-                    from .batched import BatchedARDGP
-                    bg = BatchedARDGP(optimizer=None)
-                    bg.models = [self.gp_models[n] for n in names]
-                    self._fused_bg = (bg, names)
+            try:
+                names = [n for n in OUTPUT_NAMES if n in self.gp_models]
+                if 2 <= len(names) <= 8:
+                    sx0 = self.scalers_X[names[0]]
+                    m0 = self.gp_models[names[0]]
+                    x0 = getattr(m0, "X_train_", None)
+                    same = x0 is not None and all(
+                        np.array_equal(self.scalers_X[n].mean_, sx0.mean_) and
+                        np.array_equal(self.scalers_X[n].scale_, sx0.scale_) and
+                        getattr(self.gp_models[n], "X_train_", np.empty(0)).shape == x0.shape and
+                        np.array_equal(self.gp_models[n].X_train_, x0) and
+                        getattr(self.gp_models[n], "_yn", np.empty((0, 0))).shape[1:] == (1,) for n in names)
+                    if same:
+                        from .batched import BatchedARDGP
+                        bg = BatchedARDGP(optimizer=None)
+                        bg.models = [self.gp_models[n] for n in names]
+                        self._fused_bg = (bg, names)
+            except Exception as e:  # noqa: BLE001 - never into the control loop: the per-model path below still serves
+                print(f"fused per-axis prediction unavailable: {e}")
         return self._fused_bg
 
     def predict_residual_batch(self, X, return_std=True):
