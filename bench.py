@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: GP predictions/s (posterior mean + variance) at N_train = 65 536, D = 9.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], SURVEY.md §8d "C3"): synthetic N_train x 9 training set with 3
-outputs, fitted once on the GPU in fp64 (Gram build + blocked Cholesky + alpha; untimed set-up,
-reported under "fit"), then every timed step predicts mean AND variance for one batch of
-M = 10 000 query points (horizon 20 x 500 rollouts) in fp32 with the queries already resident in
-HBM.  N > 1 is weak scaling: every rank holds a replica of the model and its own 10 000-query batch
-per step, and one RCCL all-gather of the [mean | var] shards closes each step (BASELINE.json
-configs[3]).  value = predictions of all ranks / max-over-ranks time.
+N > 1 runs one rank per GPU over RCCL.  Two ways in, same result: (a) the driver starts the ranks itself with
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in the
+environment), or (b) plain `python bench.py --gpus N`: this process then - BEFORE importing torch or touching the
+GPU - starts that same torch.distributed.run command as a child process, relays rank 0's single JSON line and exits
+with the child's status (a process that has initialised the GPU is never re-executed).
+
+Workload (BASELINE.json configs[2], SURVEY.md §8d "C3"): synthetic N_train x 9 training set with 3 outputs, fitted
+once on the GPU in fp64 (Gram build + blocked Cholesky + alpha; untimed set-up, reported under "fit"), then every
+timed step predicts mean AND variance for one batch of M = 10 000 query points (horizon 20 x 500 rollouts) in fp32
+with the queries already resident in HBM.  N > 1 is weak scaling: every rank holds a replica of the model (each rank
+fits redundantly: deterministic, no communication) and its own 10 000-query batch per step, and one RCCL all-gather
+of the [mean | var] shards closes each step.  value = predictions of all ranks / max-over-ranks time.
+`--workload c4` is BASELINE.json configs[3]: 1 048 576 queries in total sharded over the ranks, posterior means only,
+all-gather of the means (strong scaling).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  "roofline":     fp32 MFMA roofline of the dominant kernel (the GEMM behind V = L^-1 K*^T),
-                  measured live with HIP events on the launch stream;
-  "cpu_baseline": the reference's CPU path (scikit-learn GaussianProcessRegressor, the library the
-                  reference delegates to; falls back to the repo's NumPy oracle) on a bounded sample;
-  "fit":          Gram GB/s vs the HBM roofline and Cholesky GFLOP/s of the set-up phase.
+  "roofline":     the dominant kernel (the one GEMM launch behind |L^-1 k*|^2) against the matrix-pipe peak it
+                  runs on, its duration measured live with HIP events on the launch stream over the timed steps;
+  "cpu_baseline": the reference's CPU path (scikit-learn GaussianProcessRegressor, the library the reference
+                  delegates to; falls back to the repo's NumPy oracle) on a bounded sample;
+  "fit":          Gram GB/s vs the HBM roofline and Cholesky GFLOP/s of the set-up phase;
+  "parity":       the timed path's outputs against the fp64 path on the same batch (checked after the timed loop).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,10 +43,56 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3      # dense fp32 MFMA (= fp32 vector peak)
 MFMA_F64_PEAK_TF = 78.6       # fp64 matrix peak (MI355X datasheet; used for the Cholesky fraction only)
-# HBM/fabric bytes per launch of the dominant kernel at the default configuration, from the PMC passes
-# committed in profiles/r01_bench_pmc_hbm_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the factor 2
-# being the gfx950 FETCH_SIZE correction for 16-byte-per-lane streams (MI355X_MICROARCH.md, HBM section).
-PMC_TRAFFIC_BYTES = {("inverse", 65536, 10000): 2.951e11}
+MFMA_BF16_PEAK_TF = 2516.6    # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz (guide: "~2.5 PF dense")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.sh from --pmc passes
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-train", type=int, default=65536)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra timing of the other variance paths")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3 (default, the headline): mean+var for 10 000 queries per GPU per step, weak scaling; "
+                         "c4: BASELINE configs[3] - 1 048 576 queries in total sharded over the GPUs, posterior means "
+                         "only, RCCL all-gather of the means (strong scaling)")
+    ap.add_argument("--var-method", default="auto", choices=["auto", "inverse_split", "inverse", "solve"],
+                    help="auto = inverse_split: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch on the "
+                         "bf16 matrix pipe with both fp32 operands split exactly into three bf16 parts (fp32 accuracy); "
+                         "inverse: the same launch on the exact-fp32 MFMA; solve: blocked triangular solve chain")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """Plain `python bench.py --gpus N` with N > 1: start the ranks as a child torch.distributed.run job.  Nothing in
+    this process has imported torch or touched the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this host driver
+    env["BENCH_LAUNCHED_BY_PARENT"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for ln in p.stdout:                       # rank 0 prints exactly one JSON line; anything else goes to stderr
+        if ln.lstrip().startswith('{"metric"'):
+            lines.append(ln.strip())
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if lines:
+        print(lines[-1], flush=True)
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: the ranks finished without printing a result line\n")
+        rc = 1
+    sys.exit(rc)
 
 
 def synthetic_problem(N, M, D=9, P=3, qseed=1):
@@ -49,7 +105,7 @@ def synthetic_problem(N, M, D=9, P=3, qseed=1):
     return X, Y, Xq
 
 
-def cpu_baseline(M_sample=2000, N_sample=8192):
+def cpu_baseline(M_sample=2000, N_sample=8192, n_full=65536):
     """Reference CPU path on a bounded sample: fit at N_sample (untimed), then time
     predict(return_std=True) for M_sample queries."""
     X, Y, Xq = synthetic_problem(N_sample, M_sample)
@@ -77,30 +133,69 @@ def cpu_baseline(M_sample=2000, N_sample=8192):
         what = "oracle/gp_oracle.py (NumPy/SciPy restatement)"
     v = M_sample / t_pred
     return {"value": v, "unit": "predictions/s", "cores": cores, "kind": kind,
-            "sample": f"{what}: predict(return_std=True) of {M_sample} queries at N_train={N_sample} (not 65536: the "
-                      f"CPU fit alone would take ~10 min and 100 GB); fit {t_fit:.1f} s untimed, predict {t_pred:.2f} s; "
-                      f"cost grows as N_train^2, i.e. ~{v * (N_sample / 65536.0) ** 2:.1f} predictions/s "
-                      f"extrapolated to N_train=65536",
+            "n_train_of_sample": N_sample,
+            # predict cost grows as N_train^2 (the triangular solve): the like-for-like figure at the headline size
+            "extrapolated_value_at_n_train": {"n_train": n_full, "value": v * (N_sample / float(n_full)) ** 2,
+                                              "rule": "value x (n_train_of_sample / n_train)^2"},
+            "sample": f"{what}: predict(return_std=True) of {M_sample} queries at N_train={N_sample} (not {n_full}: the "
+                      f"CPU fit alone would take ~10 min and 100 GB); fit {t_fit:.1f} s untimed, predict {t_pred:.2f} s",
             "fit_seconds_at_sample": t_fit}
 
 
+def cpu_full_size_predict(dev, X, y_mean, y_std, alpha_host, ls, noise, M_cpu=200):
+    """A measured (not extrapolated) CPU figure at the headline N_train: scikit-learn's predict(return_std=True) on a
+    regressor object that carries the factor computed on the GPU (L_ downloaded once, untimed) - the reference's
+    predict arithmetic (`_gpr.py:441-494`: kernel_(X, X_train_), K_trans @ alpha_, solve_triangular(L_, K_trans.T),
+    einsum) on the host cores.  Only when the host has the memory for the 34 GB factor."""
+    try:
+        import psutil
+        from sklearn.gaussian_process import GaussianProcessRegressor as SkGPR
+        from sklearn.gaussian_process.kernels import RBF as SkRBF, WhiteKernel as SkWhite
+    except ImportError as e:
+        return {"skipped": f"{e}"}
+    need = dev.N * dev.N * 8
+    avail = psutil.virtual_memory().available
+    if avail < 2.5 * need:
+        return {"skipped": f"host memory: {avail / 1e9:.0f} GB available, {2.5 * need / 1e9:.0f} GB wanted"}
+    import torch
+    t0 = time.perf_counter()
+    Lh = torch.empty((dev.N, dev.N), dtype=torch.float64)
+    rows = 8192
+    for r0 in range(0, dev.N, rows):           # (strided device rows -> contiguous host rows, block by block)
+        Lh[r0:r0 + rows].copy_(dev.K[r0:r0 + rows, : dev.N])
+    t_dl = time.perf_counter() - t0
+    kern = SkRBF(ls) + SkWhite(noise)
+    gp = SkGPR(kernel=kern, alpha=1e-4, normalize_y=True, optimizer=None)
+    gp.kernel_ = kern
+    gp.X_train_, gp.L_, gp.alpha_ = X, Lh.numpy(), alpha_host
+    gp._y_train_mean, gp._y_train_std = y_mean, y_std
+    gp.y_train_ = np.zeros((dev.N, alpha_host.shape[1]))
+    gp.n_features_in_ = X.shape[1]
+    Xq = np.random.default_rng(1).standard_normal((M_cpu, X.shape[1]))
+    t0 = time.perf_counter()
+    mean, std = gp.predict(Xq, return_std=True)
+    t_pred = time.perf_counter() - t0
+    return {"value": M_cpu / t_pred, "unit": "predictions/s", "n_train": dev.N, "queries": M_cpu,
+            "predict_seconds": t_pred, "factor_download_seconds": t_dl, "mean": mean, "std": std, "Xq": Xq}
+
+
+def pmc_traffic(kernel_key, N, M):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed --pmc passes (separate rocprofv3 runs:
+    the counters cannot be collected inside this process), or None when no pass exists for this kernel and shape."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            for e in json.load(f)["entries"]:
+                if e["kernel_key"] == kernel_key and e["n_train"] == N and e["queries"] == M:
+                    return e
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n-train", type=int, default=65536)
-    ap.add_argument("--queries", type=int, default=10000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-split", action="store_true", help="skip the extra timing of the bf16x3-split variance path")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
-                    help="c3 (default, the headline): mean+var for 10 000 queries per GPU per step, weak scaling; "
-                         "c4: BASELINE configs[3] - 1 048 576 queries in total sharded over the GPUs, posterior means "
-                         "only, RCCL all-gather of the means (strong scaling)")
-    ap.add_argument("--var-method", default="inverse", choices=["inverse", "solve"],
-                    help="inverse: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch (default); "
-                         "solve: blocked triangular solve chain")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)                     # does not return
 
     import torch
     import torch.distributed as dist
@@ -108,12 +203,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} visible ({torch.cuda.device_count()} devices)")
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank,
     # so the single-GPU box exercises the same RCCL all-gather path the 2/4/8-GPU runs use
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    ranks_seen = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -124,23 +222,26 @@ def main():
         os.dup2(2, 1)
         try:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(8, device=torch.device("cuda", local_rank))
-            dist.all_reduce(warm)
+            ones = torch.ones(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(ones)                                   # RCCL all-reduce: every rank really is there
+            ranks_seen = int(round(float(ones.item())))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
 
     from unmanned_aerial_vehicles_amd import _lib
-    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend, padded
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
     from unmanned_aerial_vehicles_amd.sharded import all_gather_rows
 
     be = get_backend(local_rank)
     c4 = args.workload == "c4"
     if c4:
         args.queries = (1 << 20) // world          # strong scaling: the 1 M queries are split over the ranks
+    method = "inverse_split" if args.var_method == "auto" else args.var_method
     N, M, D, P = args.n_train, args.queries, 9, 3
     X, Y, _ = synthetic_problem(N, 1)
     Yn = (Y - Y.mean(0)) / Y.std(0)
@@ -157,17 +258,13 @@ def main():
 
     # ---------------------------------------------------------------- fit (set-up, timed separately)
     dev = DeviceGP(X, Yn, be)
+    dev.timing(True)
     dev.gram(ls, sf2, noise + jitter)            # warm-up of the Gram kernel + allocation
     torch.cuda.synchronize()
-    gram_times = []
-    for _ in range(3):                             # median of 3 launches (HIP events on the launch stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    for _ in range(3):
         dev.gram(ls, sf2, noise + jitter)
-        e1.record()
-        torch.cuda.synchronize()
-        gram_times.append(e0.elapsed_time(e1) * 1e-3)
-    gram_s = sorted(gram_times)[1]
+    gram_times = dev.kernel_times(_lib.GPK_TIMED_GRAM)[-3:] * 1e-3     # HIP events around the Gram kernel launches
+    gram_s = float(sorted(gram_times)[1])                               # median of 3
     gram_bytes = dev.Np * dev.Np * 8 + N * D * 8          # N^2 s + N D s (s = 8)
     info = C.c_int(0)
     t0 = time.perf_counter()
@@ -176,22 +273,24 @@ def main():
     torch.cuda.synchronize()
     potrf_s = time.perf_counter() - t0
     dev.factored = True
-    if not c4 and args.var_method == "inverse":
+    use_w = not c4 and method in ("inverse", "inverse_split")
+    if use_w:
         # the inverse factor (34 GB) and its scratch come from torch's caching allocator: map them once outside the
         # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
         warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64)]
         del warm
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if c4:
-        trtri_s = None                             # means only: no variance preparation
-    elif args.var_method == "inverse":
+    trtri_s = None
+    if use_w:
         dev.inverse_factor(False)                  # W = L^-1 on the fp64 MFMA (N^3/3 flops) ...
         torch.cuda.synchronize()
         trtri_s = time.perf_counter() - t0
-        dev.inverse_factor(True)                   # ... kept as an fp32 copy for serving
-    else:
-        trtri_s = None
+        if method == "inverse_split":
+            dev.split_inverse_factor()             # ... served as three exact bf16 parts per entry (6 bytes)
+        else:
+            dev.inverse_factor(True)               # ... served as an fp32 copy
+    elif not c4:
         dev._f32_factor()                          # fp32 copies of L / leaf inverses
     torch.cuda.synchronize()
     prep_s = time.perf_counter() - t0
@@ -199,8 +298,6 @@ def main():
     dev.solve_alpha()                              # two launches through W when it exists, else the solve chain
     torch.cuda.synchronize()
     alpha_s = time.perf_counter() - t0
-    if args.var_method == "inverse" and not c4:
-        dev._Winv.pop("f64", None)                 # the fp64 inverse is not needed for fp32 serving
     dev._f32_data()
     torch.cuda.synchronize()
     fit = {"n_train": N, "dtype": "f64",
@@ -210,10 +307,12 @@ def main():
            "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
            "alpha_solve_ms": alpha_s * 1e3,
            "variance_prep": "none (means only)" if c4 else
-                            ("explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy"
-                             if args.var_method == "inverse" else "fp32 copy of L"),
+                            {"inverse_split": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + exact bf16x3 split",
+                             "inverse": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy",
+                             "solve": "fp32 copy of L"}[method],
            "variance_prep_s": prep_s, "trtri_s": trtri_s,
-           "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None}
+           "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None,
+           "replicated_per_rank": world > 1}
 
     # ---------------------------------------------------------------- the timed hot path
     kss = sf2 + noise
@@ -225,7 +324,7 @@ def main():
 
     def step_c3():
         mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4
-        var = dev.predict_var_dev(q32, kss, 0.0, "float32", args.var_method)        # K5
+        var = dev.predict_var_dev(q32, kss, 0.0, "float32", method)                 # K5
         out = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1)      # (M, 2P)
         if use_dist:
             out = all_gather_rows(out, M * world)                                   # RCCL all-gather
@@ -235,27 +334,47 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    dev.timing(True)                               # restart the event ring: it now covers exactly the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync_all()
     dt = time.perf_counter() - t0
+    k5_ms = dev.kernel_times(_lib.GPK_TIMED_K5)    # the dominant launch of every timed step (the last 64 of them)
+    dev.timing(False)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=be.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(out).all()), "non-finite predictions"
 
+    # ---------------------------------------------------------------- parity of the timed path (outside the timed region)
+    # rank 0's own shard of the last step against the fp64 kernels on the same batch: the stated fp32 bars
+    # (mean 1e-4, std 1e-3, relative) at the headline shape itself
+    parity = None
+    if rank == 0:
+        mine = out[:M].double() if use_dist else out.double()
+        m64 = dev.predict_mean_dev(q32.double(), y_mean, y_std, "float64")
+        if c4:
+            e_mean = float((mine - m64).abs().max() / m64.abs().max())
+            parity = {"mean_max_rel_err_vs_fp64": e_mean, "mean_tol": 1e-4, "ok": e_mean < 1e-4}
+        else:
+            v64 = dev.predict_var_dev(q32.double(), kss, 0.0, "float64", "inverse" if use_w else "solve")
+            s64 = torch.sqrt(v64[:, None] * ystd2[None, :])
+            e_mean = float((mine[:, :P] - m64).abs().max() / m64.abs().max())
+            e_std = float(((torch.sqrt(mine[:, P:]) - s64).abs() / s64).max())
+            parity = {"mean_max_rel_err_vs_fp64": e_mean, "std_max_rel_err_vs_fp64": e_std, "mean_tol": 1e-4,
+                      "std_tol": 1e-3, "queries_checked": M, "ok": e_mean < 1e-4 and e_std < 1e-3}
+        assert parity["ok"], f"timed path disagrees with the fp64 path: {parity}"
+    if not c4:
+        dev._Winv.pop("f64", None)                 # 34 GB back before the extras
+
     # ---------------------------------------------------------------- roofline of the dominant kernel
-    # inverse: ONE launch of gemm_kernel<float,false,false,1> per step (V = W K*^T reduced to column
-    # sums of squares in its epilogue); solve: 1023 launches of gemm_kernel<float,false,true,0>.
-    # The K5 call is bracketed with HIP events on the launch stream; besides the GEMM it contains the
-    # K*-build (~1 ms) and two tiny reductions, so the figure is slightly conservative.
     roof = None
     if rank == 0 and c4:
         # K4: algorithmic flops M N (3D + 2P + 8) against the fp32 vector peak.  The MFMA kernel moves the 3D
-        # distance flops to the (bf16) matrix pipe, so it can exceed the vector peak; what bounds it is the
-        # vector ALU's exp + P FMAs per pair.
+        # distance flops to the (bf16) matrix pipe, so the ratio is NOT a roofline fraction of one pipe: what bounds
+        # the kernel is the vector ALU's exp + P FMAs per pair; `frac` is therefore null.
         flops = float(M) * N * (3 * D + 2 * P + 8)
         kern = dev.mean_kernel_choice()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -264,53 +383,55 @@ def main():
         b.record()
         torch.cuda.synchronize()
         k4_s = a.elapsed_time(b) * 1e-3
+        valu_flops = float(M) * N * (2 * P + 8)          # exp2 (counted 8) + P FMAs per pair stay on the vector ALU
         roof = {"bound": "valu",
                 "kernel": "mean_bf16_kernel<3,2> (distances: 6 x v_mfma_f32_32x32x16_bf16 per 32x32 block, exact bf16x3 "
                           "operand split; exp2 + P FMAs per pair on the VALU)" if kern == "mfma"
                 else "predict_mean_kernel<float,3,1> (exact differences on the VALU)",
-                "achieved": flops / k4_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / k4_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "k4_ms": k4_s * 1e3,
-                "algorithmic_flops_per_step": flops}
+                "achieved": (valu_flops if kern == "mfma" else flops) / k4_s / 1e12, "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s",
+                "frac": (valu_flops if kern == "mfma" else flops) / k4_s / 1e12 / MFMA_F32_PEAK_TF,
+                "note": "vector-ALU flops only (exp2 counted as 8 + 2P per pair); the 3D distance flops per pair run "
+                        "on the bf16 matrix pipe" if kern == "mfma" else "all flops on the vector ALU",
+                "algorithmic_TFLOPs_all_pipes": flops / k4_s / 1e12,
+                "traffic": None, "k4_ms": k4_s * 1e3, "algorithmic_flops_per_step": flops}
     if rank == 0 and not c4:
-        Mp = padded(M)
-        lsv = np.full(D, ls)
-        lsp = lsv.ctypes.data_as(_lib._dp)
-        work = torch.empty((dev.Np * Mp,), dtype=torch.float32, device=be.device)
-        var = torch.empty((Mp,), dtype=torch.float64, device=be.device)
-        Xf = dev._f32_data()["X"]
-        reps, tot = 3, 0.0
-        for _ in range(reps):
-            be.bind_stream()
+        flops = float(N) * float(N) * float(M)      # N^2 flops per prediction (K5), fp32-equivalent
+        k5_s = float(np.mean(k5_ms)) * 1e-3 if len(k5_ms) else float("nan")
+        if method == "solve":                       # the chain's launches are not bracketed one by one: time the call
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            if args.var_method == "inverse":
-                Wf = dev.inverse_factor(True)
-                be.check(be.lib.gpk_predict_var_inv(be.h, _lib.GPK_F32, C.c_void_p(Xf.data_ptr()), N, D, lsp, sf2,
-                                                    C.c_void_p(Wf.data_ptr()), dev.Np, dev.Np,
-                                                    C.c_void_p(q32.data_ptr()), M, kss, 0.0,
-                                                    C.c_void_p(work.data_ptr()), C.c_void_p(var.data_ptr())))
-            else:
-                c = dev._f32_factor()
-                be.check(be.lib.gpk_predict_var(be.h, _lib.GPK_F32, C.c_void_p(Xf.data_ptr()), N, D, lsp, sf2,
-                                                C.c_void_p(c["L"].data_ptr()), dev.Np, dev.Np,
-                                                C.c_void_p(c["winv"].data_ptr()), C.c_void_p(q32.data_ptr()), M, kss,
-                                                0.0, C.c_void_p(work.data_ptr()), C.c_void_p(var.data_ptr())))
+            dev.predict_var_dev(q32, kss, 0.0, "float32", "solve")
             b.record()
             torch.cuda.synchronize()
-            tot += a.elapsed_time(b) * 1e-3
-        k5_s = tot / reps
-        flops = float(N) * float(N) * float(M)      # N^2 flops per prediction (K5)
-        n_launch = 1 if args.var_method == "inverse" else 2 * (dev.Np // 128) - 1
-        roof = {"bound": "mfma",
-                "kernel": "gemm_kernel<float,false,false,1> (V = W K*^T with fused column-norm epilogue, 1 launch/step)"
-                          if args.var_method == "inverse" else
-                          "gemm_kernel<float,false,true,0> (all launches of the triangular solve)",
-                "achieved": flops / k5_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / k5_s / 1e12 / MFMA_F32_PEAK_TF,
-                "traffic": PMC_TRAFFIC_BYTES.get((args.var_method, N, M)),
-                "launches_per_step": n_launch, "k5_ms": k5_s * 1e3,
-                "algorithmic_flops_per_step": flops}
-        del work, var
+            k5_s = a.elapsed_time(b) * 1e-3
+        if method == "inverse_split":
+            # every fp32-equivalent multiply-add is six bf16 MFMA multiply-adds (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0)
+            key, peak = "k5_split_kernel", MFMA_BF16_PEAK_TF
+            executed = 6.0 * flops
+            kernel = ("k5_split_kernel<4> (V = W K*^T, fp32 operands as 3 exact bf16 parts, 6 x v_mfma_f32_32x32x16_bf16 per "
+                      "32x32x16 block product, fp32 accumulation, fused column-norm epilogue, 1 launch/step)")
+        else:
+            key, peak = ("gemm_kernel_f32_epi1", MFMA_F32_PEAK_TF)
+            executed = flops
+            kernel = ("gemm_kernel<float,false,false,1> (V = W K*^T on v_mfma_f32_32x32x2_f32 with fused column-norm "
+                      "epilogue, 1 launch/step)" if method == "inverse" else
+                      "gemm_kernel<float,false,true,0> (all launches of the triangular solve)")
+        tr = pmc_traffic(key, N, M)
+        roof = {"bound": "mfma", "kernel": kernel,
+                "achieved": executed / k5_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": executed / k5_s / 1e12 / peak,
+                "pipe": "bf16 MFMA" if method == "inverse_split" else "fp32 MFMA",
+                "algorithmic_flops_per_launch": executed,
+                "algorithmic_flops_note": "N^2 M fp32-equivalent flops (SURVEY 8d)" +
+                                          (" x 6 bf16 MFMA products per fp32-equivalent product" if method == "inverse_split" else ""),
+                "fp32_equivalent_TFLOPs": flops / k5_s / 1e12,
+                "traffic": tr["bytes_per_launch"] if tr else None,
+                "traffic_source": tr["source"] if tr else None,
+                "launches_per_step": 1 if method != "solve" else 2 * (dev.Np // 128) - 1,
+                "kernel_ms": k5_s * 1e3, "kernel_ms_min_max": [float(np.min(k5_ms)), float(np.max(k5_ms))] if len(k5_ms) else None,
+                "timed_launches": int(len(k5_ms)),
+                "timing": "HIP events recorded by the library around the launch on its stream, over the timed steps"}
 
     # host-boundary rate (not the headline): queries start in host memory, results end in host memory
     host_api = None
@@ -322,45 +443,40 @@ def main():
             t0 = time.perf_counter()
             qd = torch.from_numpy(xq_host).to(be.device)
             mean = dev.predict_mean_dev(qd, y_mean, y_std, "float32")
-            var = dev.predict_var_dev(qd, kss, 0.0, "float32", args.var_method)
+            var = dev.predict_var_dev(qd, kss, 0.0, "float32", method)
             res = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1).cpu().numpy()
             ts.append(time.perf_counter() - t0)
         host_api = {"ms_per_batch": min(ts) * 1e3, "predictions_per_s": M / min(ts),
                     "note": "PCIe-inclusive: 10 000 x 9 fp32 queries host->HBM, (10 000 x 6) fp64 results HBM->host"}
         assert np.isfinite(res).all()
 
-    # ---------------------------------------------------------------- extra: K5 on the bf16 pipe (exact split)
-    # Not the headline: `value` above is the fp32-MFMA path.  The same variance through six bf16 MFMAs per block
-    # product on operands split exactly into three bf16 parts (fp32 accuracy) is timed beside it.
-    split_info = None
-    if rank == 0 and world == 1 and not c4 and args.var_method == "inverse" and not args.no_split:
+    # ---------------------------------------------------------------- extra: the exact-fp32 MFMA form of the same launch
+    extras = None
+    if rank == 0 and world == 1 and not c4 and method == "inverse_split" and not args.no_extras:
         try:
-            dev.split_inverse_factor()
-            vs = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split")
-            v32 = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse")
+            dev.inverse_factor(True)               # fp32 copy of W (recomputes W on the fp64 MFMA: untimed)
+            dev._Winv.pop("f64", None)
+            dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse")
             torch.cuda.synchronize()
             ts = []
             for _ in range(3):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 dev.predict_mean_dev(q32, y_mean, y_std, "float32")
-                dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split")
+                v32 = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse")
                 b.record()
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b) * 1e-3)
-            t_split = sorted(ts)[1]
-            split_info = {
-                "what": "mean + variance with the variance GEMM on the bf16 matrix pipe: fp32 operands split exactly "
-                        "into 3 bf16 parts (round to nearest), 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block product, "
-                        "fp32 accumulation",
-                "ms_per_step": t_split * 1e3, "predictions_per_s": M / t_split,
-                "fp32_equivalent_TFLOPs": float(N) * N * M / t_split / 1e12,
-                "bf16_mfma_TFLOPs": 6.0 * float(N) * N * M / t_split / 1e12, "bf16_mfma_peak_TFLOPs": 2516.0,
-                "max_abs_var_diff_vs_fp32_mfma_path": float(torch.max(torch.abs(vs - v32))),
-                "var_range": [float(torch.min(v32)), float(torch.max(v32))]}
-            dev._Winv.pop("split", None)
-        except Exception as e:  # noqa: BLE001 - the extra must never take the headline down
-            split_info = {"error": repr(e)}
+            t32 = sorted(ts)[1]
+            extras = {"fp32_mfma_path": {
+                "what": "mean + variance with the variance GEMM on v_mfma_f32_32x32x2_f32 (round 1's headline path; "
+                        "--var-method inverse)",
+                "ms_per_step": t32 * 1e3, "predictions_per_s": M / t32,
+                "fp32_mfma_TFLOPs": float(N) * N * M / t32 / 1e12, "frac_of_fp32_mfma_peak": float(N) * N * M / t32 / 1e12 / MFMA_F32_PEAK_TF,
+                "max_abs_var_diff_vs_timed_path": float(torch.max(torch.abs(v32 * float(y_std[0] ** 2) - out[:M, P].double())))}}
+            dev._Winv.pop("f32", None)
+        except Exception as e:  # noqa: BLE001 - an extra must never take the headline down
+            extras = {"error": repr(e)}
 
     if rank == 0:
         total_pred = float(M) * world * args.steps
@@ -368,7 +484,7 @@ def main():
             "metric": "GP predictions/sec (mean+var) at N_train=65536, D=9" if not c4 else
                       "GP predictions/sec (posterior means, 1M queries sharded) at N_train=65536, D=9",
             "value": total_pred / dt, "unit": "predictions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if c4 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"C3: N_train={N}, D={D}, P={P}, batched predict mean+var over {M} query points "
@@ -377,16 +493,33 @@ def main():
                                    (f"C4: N_train={N}, D={D}, P={P}, {M * world} queries sharded over {world} GPU(s), "
                                     f"posterior means, fp32, all-gather of the means"),
                        "n_train": N, "features": D, "outputs": P, "queries_per_gpu_per_step": M,
-                       "parallelism": f"query-sharded x{world}, model replicated" +
+                       "variance_path": None if c4 else method,
+                       "arithmetic": "fp32 operands and accumulation" +
+                                     ("; products on the bf16 MFMA pipe from an exact 3-way bf16 split of every fp32 "
+                                      "operand (error class of the fp32 MFMA, checked under \"parity\")"
+                                      if (method == "inverse_split" and not c4) else ""),
+                       "parallelism": f"query-sharded x{world}, model replicated (every rank fits redundantly)" +
                                       ((", RCCL all-gather of the means" if c4 else ", RCCL all-gather of [mean|var]")
                                        if use_dist else "")},
             "roofline": roof,
+            "parity": parity,
             "fit": fit,
             "host_api": host_api,
-            "bf16x3_split": split_info,
+            "extras": extras,
         }
         if not args.no_cpu_baseline and world == 1 and not c4:     # reported baseline: rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline(n_full=N)
+            try:
+                full = cpu_full_size_predict(dev, X, y_mean, y_std, dev.alpha_host(), ls, noise)
+                if "mean" in full:                                 # the CPU result doubles as one more parity check
+                    mg = dev.predict_mean_dev(full["Xq"], y_mean, y_std, "float64").cpu().numpy()
+                    full["gpu_fp64_mean_max_rel_err_vs_cpu"] = float(np.max(np.abs(mg - full["mean"])) / np.max(np.abs(full["mean"])))
+                    for k in ("mean", "std", "Xq"):
+                        full.pop(k)
+                cb["measured_at_n_train"] = full
+            except Exception as e:  # noqa: BLE001
+                cb["measured_at_n_train"] = {"skipped": repr(e)}
+            line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

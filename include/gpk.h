@@ -36,7 +36,12 @@ typedef struct gpk_context* gpk_handle;
 
 enum { GPK_F32 = 0, GPK_F64 = 1 };
 enum { GPK_OK = 0, GPK_NOT_PD = 1, GPK_BAD_ARG = 2, GPK_HIP_ERROR = 3 };
-enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_P = 16, GPK_MAX_BATCH = 8 };
+/* GPK_MAX_D: features accepted by the Gram kernels (gpk_gram, gpk_cross_gram_t and with them gpk_predict_var*).
+ * GPK_MAX_D_PREDICT: features accepted by the fused mean, the one-call serving kernels and the gradient -
+ * gpk_predict_mean*, gpk_predict_host*, gpk_lml_grad - and therefore by the composite gpk_fit / gpk_predict /
+ * gpk_lml and by the Python host side (the reference's largest model has 16 inputs,
+ * quadrotor_gp_mpc/quadrotor_gp_mpc/gaussian_process.py:66).                                                   */
+enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_D_PREDICT = 16, GPK_MAX_P = 16, GPK_MAX_BATCH = 8 };
 
 /* ---- context ------------------------------------------------------------------ */
 int gpk_create(gpk_handle* h, int device);
@@ -49,6 +54,18 @@ const char* gpk_last_error(gpk_handle h);
 int gpk_set_stream(gpk_handle h, void* stream);
 int gpk_synchronize(gpk_handle h);
 int64_t gpk_padded(int64_t n);
+
+/* ---- measurement aid -----------------------------------------------------------------------------------
+ * gpk_timing(h, 1): from now on the handle brackets its dominant launches with HIP events recorded on the
+ * handle's stream - tag GPK_TIMED_K5: the one GEMM launch of gpk_predict_var_inv / gpk_predict_var_inv_split
+ * (V = W K*^T with the column-norm epilogue); tag GPK_TIMED_GRAM: the Gram kernel of gpk_gram - and keeps the
+ * last 64 pairs.  gpk_kernel_times synchronises the stream and returns the elapsed milliseconds of the bracketed
+ * launches with that tag still in the ring, oldest first (*n_out of them, at most max_n).  bench.py uses it to
+ * report the dominant kernel's duration over exactly the timed steps; rocprofv3's kernel trace of the same run is
+ * the cross-check.  No reference counterpart (the reference has no instrumentation on this path).        */
+enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2 };
+int gpk_timing(gpk_handle h, int enable);
+int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out);
 
 /* ---- batched mode: `count` (<= 8) same-shaped problems per call --------------------------------------
  * Between gpk_batch_begin and gpk_batch_end, gpk_potrf, gpk_leaf_inverses, gpk_trtri, gpk_wtw and
@@ -125,7 +142,8 @@ int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, int64_t Mp,
 /* ---- K4: fused posterior mean -----------------------------------------------------------
  * mean[m][p] = y_mean[p] + y_std[p] * sum_j k(xq_m, x_j) alpha[j][p]; K* is never stored.
  * X dev (N x D), alpha dev (N x P), Xq dev (M x D), mean dev (M x P), all of `dtype`;
- * ls, y_mean, y_std: host double arrays.
+ * ls, y_mean, y_std: host double arrays.  D <= GPK_MAX_D_PREDICT, P <= GPK_MAX_P (GPK_BAD_ARG otherwise).
+ * Queries must be finite (the host side validates them as scikit-learn does; a NaN coordinate gives k* = 0).
  * Replaces: sklearn/gaussian_process/_gpr.py:441-447 (K_trans @ alpha_, undo normalisation);
  * the 25-call loop at src/px4/mpc.py:1490-1506; gaussian_process.py:223-226.              */
 int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,

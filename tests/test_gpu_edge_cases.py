@@ -51,6 +51,17 @@ def test_empty_query_batch_and_wrong_width():
         _fit(X, Y[:10], 1.0, 0.1)
     with pytest.raises(ValueError):
         _fit(np.full((5, 2), np.nan), np.zeros(5), 1.0, 0.1)
+    # non-finite queries are refused as scikit-learn refuses them (its check_array), not mapped to the prior
+    bad = np.zeros((3, 4))
+    bad[1, 2] = np.nan
+    with pytest.raises(ValueError, match="NaN or infinity"):
+        g.predict(bad)
+    bad[1, 2] = np.inf
+    with pytest.raises(ValueError, match="NaN or infinity"):
+        g.predict(bad, return_std=True)
+    # more than 16 features: refused when the model is built (every predict / gradient kernel is compiled for D <= 16)
+    with pytest.raises(ValueError, match="D must be in"):
+        _fit(rng.standard_normal((40, 17)), rng.standard_normal(40), 1.0, 0.1)
 
 
 def test_duplicates_and_not_positive_definite():

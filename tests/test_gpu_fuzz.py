@@ -1,0 +1,145 @@
+"""Bounded randomised parity sweep (fixed seeds) through the estimator seam, the ROS-package GP and the fused
+per-axis models against the CPU oracle, with every fresh device buffer poisoned (GPK_DEBUG_FILL=nan, conftest).
+Random N (tile edges included), M, D <= 16, P <= 12, isotropic / ARD, sf2, noise, target normalisation, predict
+dtype and variance method.  The pass bars are the DOCUMENTED tolerances:
+
+    fp64:  mean 1e-8, std 1e-7, LML 1e-9, gradient 1e-6 (relative, max-norm)
+    fp32:  mean 1e-4, std 1e-3 - with the fp32 serving gates of DeviceGP active: a model whose mean would leave
+           1e-4 in fp32 (sum_j |k*_j alpha_j| >> |mean|: noise ~ 1e-3) is served by the fp64 kernels instead, and
+           single queries with a variance below 5e-3 of the prior's are recomputed in fp64.
+
+`tools/fuzz_parity.py` is the long-running form of the same sweep (more and larger cases)."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EDGE = [1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 1023, 1024, 1025,
+        2047, 2048, 2049]
+
+
+def _pick(rng, hi):
+    if rng.random() < 0.5:
+        return int(rng.choice([e for e in EDGE if e <= hi]))
+    return int(rng.integers(1, hi + 1))
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fuzz_estimator_against_oracle(seed):
+    from unmanned_aerial_vehicles_amd import RBF, ConstantKernel, GaussianProcessRegressor, WhiteKernel
+    rng = np.random.default_rng(1000 + seed)
+    fails, served32, gated = [], 0, 0
+    for c in range(20):
+        N, M = _pick(rng, 2500), _pick(rng, 2500)
+        D, P = int(rng.integers(1, 17)), int(rng.integers(1, 13))
+        ard = rng.random() < 0.4
+        ls = (np.exp(rng.uniform(np.log(0.6), np.log(3.0), D)) * np.sqrt(D) / 2 if ard
+              else float(np.exp(rng.uniform(np.log(0.6), np.log(3.0))) * np.sqrt(D) / 2))
+        sf2 = float(np.exp(rng.uniform(-1, 1))) if rng.random() < 0.5 else 1.0
+        noise = float(np.exp(rng.uniform(np.log(1e-3), np.log(0.3))))
+        normalize = bool(rng.random() < 0.5)
+        pd = "float32" if rng.random() < 0.5 else "float64"
+        vm = str(rng.choice(["auto", "inverse", "solve"] + (["inverse_split"] if pd == "float32" else [])))
+        X = rng.standard_normal((N, D))
+        Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+        Xq = rng.standard_normal((M, D)) * rng.choice([0.5, 1.0, 2.0])
+        kern = RBF(ls) + WhiteKernel(noise)
+        if sf2 != 1.0:
+            kern = ConstantKernel(sf2) * RBF(ls) + WhiteKernel(noise)
+        tag = f"seed {seed} case {c}: N={N} M={M} D={D} P={P} ard={ard} sf2={sf2:.3g} noise={noise:.3g} norm={normalize} {pd} {vm}"
+        g = GaussianProcessRegressor(kernel=kern, alpha=1e-8, normalize_y=normalize, optimizer=None, predict_dtype=pd,
+                                     var_method=vm).fit(X, Y)
+        mean, std = g.predict(Xq, return_std=True)
+        mean_only = g.predict(Xq)
+        lml = g.log_marginal_likelihood_value_
+        lml2, grad = g.log_marginal_likelihood(g.kernel_.theta, eval_gradient=True)
+        st = O.fit_fixed(X, Y, ls, sf2, noise, 1e-8, normalize)
+        om, os_ = O.predict(st, Xq, return_std=True)
+        olml, ograd = O.log_marginal_likelihood(st), O.lml_gradient(st, ard=ard)
+        mean, std, om, os_ = (np.asarray(a).reshape(M, -1) for a in (mean, std, om, os_))
+        grad = np.asarray(grad)[1:] if len(grad) == len(ograd) + 1 else np.asarray(grad)   # leading ConstantKernel term
+        e = {"mean": _rel(mean, om), "std": _rel(std, os_), "lml": abs(lml - olml) / abs(olml),
+             "lml2": abs(lml2 - lml) / abs(lml), "grad": _rel(grad, np.asarray(ograd))}
+        if pd == "float32":
+            ok32 = g._dev.fp32_mean_ok()
+            served32 += ok32
+            gated += not ok32
+            tol = {"mean": 1e-4, "std": 1e-3}
+        else:
+            tol = {"mean": 1e-8, "std": 1e-7}
+        tol.update(lml=1e-9, lml2=1e-9, grad=1e-6)
+        bad = [k for k in tol if not e[k] < tol[k]]
+        if not np.array_equal(np.asarray(mean_only).reshape(M, -1), mean):
+            bad.append("mean-only call differs from the mean of the mean+std call")
+        if bad:
+            fails.append(tag + "  " + ", ".join(f"{k} {e.get(k, '')}" for k in bad))
+    assert not fails, "\n".join(fails)
+    assert served32 >= 3, "the fp32 kernels must actually have served some of the fp32 cases"
+
+
+def test_fuzz_package_gp_and_fused_models():
+    from unmanned_aerial_vehicles_amd import BatchedARDGP, GaussianProcess
+    rng = np.random.default_rng(77)
+    fails = []
+    for c in range(8):                                   # gaussian_process.py:63-265
+        N, M = _pick(rng, 1500), _pick(rng, 500)
+        D, P = int(rng.integers(1, 17)), int(rng.integers(1, 13))
+        ls = float(np.exp(rng.uniform(np.log(0.6), np.log(3.0))) * np.sqrt(D) / 2)
+        sf2, noise = float(np.exp(rng.uniform(-1, 1))), float(np.exp(rng.uniform(np.log(1e-3), np.log(0.3))))
+        X = rng.standard_normal((N, D))
+        Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+        Xq = rng.standard_normal((M, D))
+        gp = GaussianProcess(input_dim=D, output_dim=P)
+        gp.max_data_points = 10 ** 9
+        gp.kernel.length_scale, gp.kernel.signal_variance, gp.noise_variance = ls, sf2, noise
+        gp.add_training_data(X, Y)
+        gp.fit()
+        m, v = gp.predict(Xq)
+        if N < 2:                                        # the reference refuses to fit and predicts the prior
+            ok = np.all(m == 0) and np.allclose(v, sf2)
+        else:
+            o = O.PackageGPOracle(ls, sf2, noise).fit(X, Y)
+            om, ov = o.predict(Xq)
+            e_lml = abs(gp.log_marginal_likelihood() - o.log_marginal_likelihood()) / abs(o.log_marginal_likelihood())
+            ok = _rel(m, om) < 1e-8 and _rel(v, ov) < 1e-7 and e_lml < 1e-9 and v.shape == (M, P)
+        if not ok:
+            fails.append(f"package case {c}: N={N} M={M} D={D} P={P} ls={ls:.3g} sf2={sf2:.3g} noise={noise:.3g}")
+    for c in range(6):                                   # gp_trainer.py / pretrained_gp.py: per-axis models together
+        N, M = max(_pick(rng, 1500), 3), int(rng.integers(1, 41))
+        D, B = int(rng.integers(1, 17)), int(rng.integers(2, 9))
+        X = rng.standard_normal((N, D))
+        Y = np.sin(X @ rng.standard_normal((D, B))) + 0.1 * rng.standard_normal((N, B))
+        Xq = rng.standard_normal((M, D))
+        normalize = bool(rng.random() < 0.5)
+        bg = BatchedARDGP(length_scale=np.full(D, np.sqrt(D)), noise_level=0.05, alpha=1e-8, normalize_y=normalize,
+                          optimizer=None).fit(X, Y)
+        th = bg.thetas + rng.uniform(-0.4, 0.4, bg.thetas.shape)       # distinct hyper-parameters per model
+        lml_f, grad_f = bg.log_marginal_likelihood(th, eval_gradient=True, fused=True)    # odd N included
+        lss, noises = [], []
+        for b, m_ in enumerate(bg.models):
+            m_.kernel_.theta = th[b]
+            m_._refactor()
+            comp = m_.kernel_.components()
+            lss.append(comp.ls_vector(D))
+            noises.append(comp.noise)
+        bg._fused = None
+        mean, std = bg.predict(Xq, return_std=True)
+        e_mean = e_std = e_lml = e_grad = 0.0
+        for b in range(B):
+            st = O.fit_fixed(X, Y[:, b], lss[b], 1.0, noises[b], 1e-8, normalize)
+            om, os_ = O.predict(st, Xq, return_std=True)
+            e_mean, e_std = max(e_mean, _rel(mean[:, b], om.ravel())), max(e_std, _rel(std[:, b], os_.ravel()))
+            olml = O.log_marginal_likelihood(st)
+            e_lml = max(e_lml, abs(lml_f[b] - olml) / abs(olml))
+            e_grad = max(e_grad, _rel(grad_f[b], O.lml_gradient(st, ard=True)))
+        used = M <= 32 and bg._serve is not None and bg._serve.get("ok", False)
+        if not (e_mean < 1e-8 and e_std < 1e-7 and e_lml < 1e-9 and e_grad < 1e-6 and (used or M > 32)):
+            fails.append(f"batched case {c}: N={N} M={M} D={D} B={B} norm={normalize} mean {e_mean:.1e} std {e_std:.1e} "
+                         f"lml {e_lml:.1e} grad {e_grad:.1e} one-call {used}")
+    assert not fails, "\n".join(fails)

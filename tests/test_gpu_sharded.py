@@ -1,0 +1,88 @@
+"""RCCL tests of the query-sharded predict path on real GPUs: `ShardedPredictor` (libgpk launches followed by
+`all_gather_into_tensor` on the same torch stream) under the `nccl` backend - one rank on the one-GPU box, two ranks
+where two GPUs are visible - against the unsharded prediction of the same model.  The partition / padding logic
+itself is covered on CPU by tests/test_sharded_gloo.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, M, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GPK_DEBUG_FILL", "nan")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from unmanned_aerial_vehicles_amd import RBF, GaussianProcessRegressor, ShardedPredictor, WhiteKernel
+        rng = np.random.default_rng(0)
+        X = rng.standard_normal((1500, 9))
+        Y = np.sin(X @ rng.standard_normal((9, 3))) + 0.1 * rng.standard_normal((1500, 3))
+        Xq = np.random.default_rng(1).standard_normal((M, 9))
+        g = GaussianProcessRegressor(kernel=RBF(2.0) + WhiteKernel(0.1), alpha=1e-4, normalize_y=True, optimizer=None,
+                                     device=rank).fit(X, Y)
+        ref_mean, ref_std = g.predict(Xq, return_std=True)                # unsharded, fp64
+        ok = True
+        for dtype, tm, ts in (("float64", 1e-11, 1e-9), ("float32", 1e-4, 1e-3)):
+            sp = ShardedPredictor(g, dtype=dtype)
+            for _ in range(3):                                            # back-to-back steps reuse the handle's scratch
+                mean, var = sp.predict_mean_var(Xq)
+            mean2 = sp.predict_mean(Xq)
+            torch.cuda.synchronize()
+            mean, var, mean2 = mean.cpu().numpy(), var.cpu().numpy(), mean2.double().cpu().numpy()
+            e_m = np.max(np.abs(mean - ref_mean)) / np.max(np.abs(ref_mean))
+            e_s = np.max(np.abs(np.sqrt(var) - ref_std) / ref_std)
+            e_m2 = np.max(np.abs(mean2 - ref_mean)) / np.max(np.abs(ref_mean))
+            ok = ok and mean.shape == (M, 3) and e_m < tm and e_s < ts and e_m2 < tm
+        one = torch.ones(1, device=torch.device("cuda", rank))
+        dist.all_reduce(one)
+        q.put((rank, bool(ok), int(one.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, M):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), "sharded predictions differ from the unsharded model"
+    assert all(r[2] == world for r in res)
+
+
+def test_sharded_predictor_rccl_one_rank():
+    _run(1, 777)
+
+
+def test_sharded_predictor_rccl_two_ranks():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run(2, 1001)

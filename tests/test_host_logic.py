@@ -259,3 +259,47 @@ def test_shard_bounds():
                 assert cover == list(range(M))
             else:
                 assert cover[0][0] == 0 and cover[-1][1] == M and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def test_bench_self_launch_without_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus N` (N > 1, no RANK in the environment) starts the ranks as a child
+    torch.distributed.run job before torch is imported, relays rank 0's JSON line and exits with the child's
+    status."""
+    import subprocess
+    import sys
+    script = tmp_path / "drive.py"
+    script.write_text(f'''
+import io, json, os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.pop("RANK", None); os.environ.pop("WORLD_SIZE", None)
+sys.argv = ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "c4"]
+import bench
+seen = {{}}
+class FakeProc:
+    def __init__(self, cmd, stdout=None, env=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        self.stdout = io.StringIO("NCCL version banner\\n" + json.dumps({{"metric": "m", "value": 1.0, "n_gpus": 4}}) + "\\n")
+    def wait(self):
+        return 0
+bench.subprocess.Popen = FakeProc
+try:
+    bench.main()
+except SystemExit as e:
+    code = e.code
+assert "torch" not in sys.modules, "the launching parent must not import torch"
+cmd = seen["cmd"]
+assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-8:] == sys.argv[1:]
+assert os.path.basename(cmd[-9]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+print("EXIT", code)
+''')
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert out[-1] == "EXIT 0" and json_line(out[-2])["n_gpus"] == 4 and len(out) == 2      # banner went to stderr
+    assert "NCCL version banner" in r.stderr
+
+
+def json_line(s):
+    import json
+    return json.loads(s)

@@ -16,6 +16,7 @@ GPK_F32, GPK_F64 = 0, 1
 GPK_OK, GPK_NOT_PD, GPK_BAD_ARG, GPK_HIP_ERROR = 0, 1, 2, 3
 GPK_TILE, GPK_MAX_D, GPK_MAX_P = 128, 64, 16
 GPK_HOST_MAX_M = 4096
+GPK_TIMED_K5, GPK_TIMED_GRAM = 1, 2
 
 _vp, _i64, _int, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
 _dp = C.POINTER(C.c_double)
@@ -28,6 +29,8 @@ SIGNATURES = {
     "gpk_set_stream": (_int, [_vp, _vp]),
     "gpk_synchronize": (_int, [_vp]),
     "gpk_padded": (_i64, [_i64]),
+    "gpk_timing": (_int, [_vp, _int]),
+    "gpk_kernel_times": (_int, [_vp, _int, _dp, _int, C.POINTER(_int)]),
     "gpk_batch_begin": (_int, [_vp, _int]),
     "gpk_batch_buffer": (_int, [_vp, _vp, _i64]),
     "gpk_batch_end": (_int, [_vp]),

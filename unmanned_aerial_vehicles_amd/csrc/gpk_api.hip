@@ -49,6 +49,10 @@ extern "C" void gpk_destroy(gpk_handle h) {
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->serve_dev) (void)hipFree(h->serve_dev);
   if (h->serve_host) (void)hipHostFree(h->serve_host);
+  for (auto& t : h->timed) {
+    if (t.e0) (void)hipEventDestroy(t.e0);
+    if (t.e1) (void)hipEventDestroy(t.e1);
+  }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -63,6 +67,39 @@ extern "C" int gpk_set_stream(gpk_handle h, void* stream) {
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   h->stream = want;
   h->user_stream = (stream != GPK_OWN_STREAM);
+  return GPK_OK;
+}
+
+extern "C" int gpk_timing(gpk_handle h, int enable) {
+  if (!h) return GPK_BAD_ARG;
+  if (enable && h->timed.empty()) {
+    GPK_CHECK_HIP(h, hipSetDevice(h->device));
+    h->timed.resize(GPK_TIMING_RING);
+    for (auto& t : h->timed) {
+      GPK_CHECK_HIP(h, hipEventCreate(&t.e0));
+      GPK_CHECK_HIP(h, hipEventCreate(&t.e1));
+    }
+  }
+  h->timing = enable ? 1 : 0;
+  h->timed_count = 0;
+  return GPK_OK;
+}
+
+extern "C" int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, ms && n_out && max_n >= 1, "kernel_times: null pointer");
+  *n_out = 0;
+  if (h->timed.empty()) return GPK_OK;
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  const long long have = h->timed_count < GPK_TIMING_RING ? h->timed_count : GPK_TIMING_RING;
+  // oldest first among the launches still in the ring
+  for (long long i = h->timed_count - have; i < h->timed_count && *n_out < max_n; ++i) {
+    const auto& t = h->timed[(size_t)(i % GPK_TIMING_RING)];
+    if (t.tag != tag) continue;
+    float f = 0.f;
+    GPK_CHECK_HIP(h, hipEventElapsedTime(&f, t.e0, t.e1));
+    ms[(*n_out)++] = (double)f;
+  }
   return GPK_OK;
 }
 
@@ -148,7 +185,10 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
   void* partial = nullptr;
   GPK_TRY(gpk_scratch(h, (size_t)ntm * Mp * sizeof(double), &partial));
   g.C = partial;
-  GPK_TRY(gpk_gemm(h, dtype, g));
+  gpk_time_begin(h, GPK_TIMED_K5);
+  const int rc_gemm = gpk_gemm(h, dtype, g);
+  gpk_time_end(h);
+  GPK_TRY(rc_gemm);
   return gpk_colsum_finalize(h, (const double*)partial, ntm, Mp, M, kss, floor_, var);
 }
 

@@ -624,8 +624,10 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
       hipLaunchKernelGGL((gram_sym_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l,  \
                          (T)sf2, (T)diag_add, (T*)K, (long long)ldk);                                       \
   } while (0)
+  gpk_time_begin(h, GPK_TIMED_GRAM);
   if (dtype == GPK_F64) { if (stream_nt) GPK_GRAM_LAUNCH(double, true); else GPK_GRAM_LAUNCH(double, false); }
   else { if (stream_nt) GPK_GRAM_LAUNCH(float, true); else GPK_GRAM_LAUNCH(float, false); }
+  gpk_time_end(h);
 #undef GPK_GRAM_LAUNCH
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;

@@ -37,6 +37,11 @@ struct gpk_context {
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
+  // gpk_timing: HIP-event brackets around the dominant launches (K5 variance GEMM, K1 Gram kernel), a ring of pairs
+  struct TimedLaunch { hipEvent_t e0 = nullptr, e1 = nullptr; int tag = 0; };
+  int timing = 0;
+  std::vector<TimedLaunch> timed;   // GPK_TIMING_RING entries once enabled
+  long long timed_count = 0;        // launches bracketed so far (ring position = count % size)
   // batched mode (gpk_batch_begin .. gpk_batch_end): `batch` same-shaped problems per call.  Pointers passed
   // to the entry points address problem 0; a pointer that falls inside a registered buffer advances by that
   // buffer's stride per problem, any other pointer is shared by all problems.
@@ -78,6 +83,21 @@ struct gpk_context {
   } while (0)
 
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
+
+// Event brackets of gpk_timing (no-ops unless enabled): record the first event, launch, record the second.
+constexpr int GPK_TIMING_RING = 64;
+inline void gpk_time_begin(gpk_handle h, int tag) {
+  if (!h->timing) return;
+  auto& t = h->timed[(size_t)(h->timed_count % GPK_TIMING_RING)];
+  t.tag = tag;
+  (void)hipEventRecord(t.e0, h->stream);
+}
+inline void gpk_time_end(gpk_handle h) {
+  if (!h->timing) return;
+  auto& t = h->timed[(size_t)(h->timed_count % GPK_TIMING_RING)];
+  (void)hipEventRecord(t.e1, h->stream);
+  ++h->timed_count;
+}
 
 // byte stride between consecutive problems of a batch for the buffer `p` points into (0: shared / not batched)
 inline long long gpk_bstride(gpk_handle h, const void* p) {

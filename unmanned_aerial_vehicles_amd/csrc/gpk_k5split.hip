@@ -353,8 +353,10 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
   p.alpha = 1.0f;
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
+  gpk_time_begin(h, GPK_TIMED_K5);
   if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
   else hipLaunchKernelGGL(k5_split_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
+  gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);
   return gpk_colsum_finalize(h, (const double*)partial, ntmT, Mp, M, kss, floor_, var);
 }

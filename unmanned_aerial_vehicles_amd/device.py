@@ -111,6 +111,7 @@ class DeviceGP:
     # up to this padded size the inverse factor W = L^-1 is formed right away (cheap), so that alpha and
     # every later variance / gradient call are single launches
     INVERSE_EAGER_NP = 32768
+    MAX_FEATURES = 16
 
     def __init__(self, X, Yn, backend: Backend | None = None):
         torch = _torch()
@@ -121,8 +122,11 @@ class DeviceGP:
             raise ValueError("X must be (N, D) and Y (N, P)")
         self.N, self.D = X.shape
         self.P = Yn.shape[1]
-        if not (1 <= self.D <= _lib.GPK_MAX_D):
-            raise ValueError(f"D must be in [1, {_lib.GPK_MAX_D}]")
+        if not (1 <= self.D <= self.MAX_FEATURES):
+            # gpk_gram alone takes up to GPK_MAX_D = 64 features; the fused mean, the cross-Gram panel, the small-batch
+            # serving kernels and the LML gradient are compiled for D <= 16 (the reference's largest model has 16
+            # inputs, gaussian_process.py:66): refuse at construction rather than fit a model that cannot predict
+            raise ValueError(f"D must be in [1, {self.MAX_FEATURES}] on the MI355X path (got {self.D})")
         if not (1 <= self.P <= _lib.GPK_MAX_P):
             raise ValueError(f"P must be in [1, {_lib.GPK_MAX_P}]")
         self.Np = padded(self.N)
@@ -140,6 +144,7 @@ class DeviceGP:
         self._f32 = None    # dict of fp32 copies: X, alpha [, L, winv]
         self._Winv = {}     # explicit inverse factor L^-1: {'f64': tensor} and/or {'f32': tensor}
         self._host_args = None   # predict_host: cached argument addresses
+        self._amp = None         # fp32 mean gate: cached amplification estimate
         self._Kinv = None
 
     # ---- fit-side -------------------------------------------------------------------------
@@ -209,11 +214,13 @@ class DeviceGP:
                 be.bind_stream()
                 be.check(be.lib.gpk_potrs(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self.Yn), self.N,
                                           self.P, _p(self.alpha)))
+        self._amp = None
         if self._f32:
             self._f32.pop("alpha", None)       # the fp32 copy of alpha is stale; X / L copies stay valid
 
     def set_alpha(self, alpha):
         self.alpha.copy_(self.be.upload(np.asarray(alpha, dtype=np.float64).reshape(self.N, self.P)))
+        self._amp = None
         if self._f32:
             self._f32.pop("alpha", None)
 
@@ -294,6 +301,21 @@ class DeviceGP:
             raise ValueError(f"queries must be (M, {self.D})")
         return q
 
+    def timing(self, enable=True):
+        """Event brackets around the dominant launches (gpk_timing); `kernel_times(tag)` reads them back."""
+        be = self.be
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_timing(be.h, 1 if enable else 0))
+
+    def kernel_times(self, tag, max_n=64):
+        be = self.be
+        ms = np.zeros(max_n)
+        n = C.c_int(0)
+        with be.lock:
+            be.check(be.lib.gpk_kernel_times(be.h, int(tag), ms.ctypes.data_as(_lib._dp), max_n, C.byref(n)))
+        return ms[: n.value].copy()
+
     # the fp32 MFMA mean kernel expands |a - b|^2 = |a|^2 + |b|^2 - 2 a.b around the training mean; it is used
     # while the largest scaled squared norm (in exp2 units) stays below this bound (error in the exponent
     # ~ bound * 2^-22), the exact-difference kernel otherwise
@@ -307,7 +329,7 @@ class DeviceGP:
             self._r2 = {key: 0.5 * np.log2(np.e) * float(np.max(np.einsum("ij,ij->i", u, u)))}
         return "mfma" if (self.P <= 8 and self._r2[key] <= self.MFMA_MEAN_R2_MAX) else "valu"
 
-    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64", kernel="auto"):
+    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64", kernel="auto", _alpha=None):
         """K4 on device tensors; returns a (M, P) tensor of `dtype`.  kernel: "valu" (exact differences on
         the vector ALU), "mfma" (fp32 only: distances on the matrix cores) or "auto" (mfma for fp32 when
         `mean_kernel_choice` admits it)."""
@@ -327,7 +349,7 @@ class DeviceGP:
             c = self._f32_data()
             Xd, ad = c["X"], c["alpha"]
         else:
-            Xd, ad = self.X, self.alpha
+            Xd, ad = self.X, (self.alpha if _alpha is None else _alpha)     # (_alpha: fp64 weights other than alpha)
         ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
         ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
         be = self.be
@@ -419,6 +441,7 @@ class DeviceGP:
         the operand of the bf16-pipe variance launch (`method="inverse_split"`)."""
         torch = _torch()
         if "split" not in self._Winv:
+            had_f32 = "f32" in self._Winv
             Wf = self.inverse_factor(True)
             be = self.be
             W3 = be.empty((self.Np * self.Np * 6,), torch.uint8)
@@ -426,19 +449,58 @@ class DeviceGP:
                 be.bind_stream()
                 be.check(be.lib.gpk_split3(be.h, _p(Wf), self.Np, self.Np, self.Np, _p(W3)))
             self._Winv["split"] = W3
+            if not had_f32:
+                self._Winv.pop("f32", None)      # the plain fp32 copy only served as the source of the split
         return self._Winv["split"]
+
+    # ---- fp32 serving gates -------------------------------------------------------------------------------------
+    # The fp32 predict path is stated as: mean within 1e-4, std within 1e-3 (relative to the largest value) of the
+    # fp64 path.  An fp32 kernel entry carries the rounding of its squared distance (a few 1e-6 relative), so the mean
+    # error is ~5e-6 * sum_j |k*_j alpha_j| / |mean|: fine for the models the reference trains (noise 0.03-0.3), not
+    # for sf2 N / noise ~ 1e7.  `fp32_mean_amplification` measures that ratio on a sample of training rows once per
+    # alpha; the estimator routes a model above FP32_MEAN_AMP_MAX to the fp64 kernels (gpr.py).
+    FP32_MEAN_ERR_PER_AMP = 5e-6
+    FP32_MEAN_TOL = 1e-4
+    FP32_MEAN_AMP_MAX = FP32_MEAN_TOL / FP32_MEAN_ERR_PER_AMP          # = 20
+    # Variance: |W k*|^2 in fp32 is off by ~4e-6 kss (measured, N = 10^4 .. 6.5 10^4), i.e. the relative error of the
+    # standard deviation is ~2e-6 kss / var: queries whose variance is below this fraction of the prior's are
+    # recomputed in fp64 (2.5x margin to the 1e-3 bar).
+    FP32_VAR_RECHECK_FRACTION = 5e-3
+
+    def fp32_mean_amplification(self):
+        """max over a sample of <= 1024 training rows (as queries) of sum_j |k*_j| |alpha_j| divided by the largest
+        |sum_j k*_j alpha_j| of the sample: how much larger than the posterior mean the sum of the magnitudes of its
+        terms is.  Two fp64 K4 launches, cached per alpha."""
+        torch = _torch()
+        c = getattr(self, "_amp", None)            # (solve_alpha / set_alpha reset it: the library writes alpha in place)
+        if c is not None and c[0] is self.ls:
+            return c[1]
+        idx = torch.linspace(0, self.N - 1, min(self.N, 1024), device=self.be.device).round().long()
+        q = self.X[idx].contiguous()
+        zeros, ones = np.zeros(self.P), np.ones(self.P)
+        b = self.predict_mean_dev(q, zeros, ones, "float64", "valu").abs().amax(dim=0)
+        a = self.predict_mean_dev(q, zeros, ones, "float64", "valu", _alpha=self.alpha.abs()).amax(dim=0)
+        amp = float((a / b.clamp_min(1e-300)).max())
+        self._amp = (self.ls, amp)
+        return amp
+
+    def fp32_mean_ok(self):
+        return self.fp32_mean_amplification() <= self.FP32_MEAN_AMP_MAX
 
     def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64", method="auto"):
         """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units).
 
         method "solve": V = L^-1 K*^T by the blocked triangular solve (the reference's
-        solve_triangular; a chain of 2 Np/128 - 1 GEMM launches), "inverse" (= "auto"): |W k*|^2 with the
-        explicit inverse factor W = L^-1, formed once per factorisation, in ONE fused GEMM launch."""
+        solve_triangular; a chain of 2 Np/128 - 1 GEMM launches); "inverse": |W k*|^2 with the
+        explicit inverse factor W = L^-1, formed once per factorisation, in ONE fused GEMM launch (fp64 MFMA, or
+        the exact-fp32 MFMA); "inverse_split" (fp32 only): the same launch on the bf16 matrix pipe with both fp32
+        operands split exactly into three bf16 parts (fp32 accuracy, 1.5x the fp32 MFMA's speed); "auto":
+        "inverse" for fp64, "inverse_split" for fp32."""
         torch = _torch()
         assert self.factored
         f32 = dtype in ("float32", np.float32, torch.float32)
         if method == "auto":
-            method = "inverse"
+            method = "inverse_split" if f32 else "inverse"
         if method not in ("solve", "inverse", "inverse_split"):
             raise ValueError("method must be 'auto', 'solve', 'inverse' or 'inverse_split'")
         if method == "inverse_split" and not f32:

@@ -54,6 +54,7 @@ class GaussianProcessRegressor:
         self.device = device
         self.predict_dtype = predict_dtype
         self.var_method = var_method      # 'auto' | 'inverse' | 'solve' | 'inverse_split' (fp32 only): DeviceGP.predict_var_dev
+        self.fp32_gate = True             # predict_dtype="float32": route ill-conditioned models / tiny variances to fp64
         self._dev = None
 
     # ------------------------------------------------------------------ fit
@@ -200,6 +201,8 @@ class GaussianProcessRegressor:
         if return_cov:
             raise NotImplementedError("return_cov is not part of the reference's GP-MPC path")
         X = np.array(X, dtype=np.float64, ndmin=2)
+        if not np.isfinite(X).all():       # scikit-learn's input validation (_gpr.py:404-412 -> check_array)
+            raise ValueError("Input X contains NaN or infinity.")
         if not hasattr(self, "X_train_"):  # prior (unfitted) prediction, _gpr.py:416-440
             n_t = self.n_targets if self.n_targets is not None else 1
             kern = self.kernel if self.kernel is not None else (
@@ -227,14 +230,30 @@ class GaussianProcessRegressor:
                 mean, var = mean[:, 0], var[:, 0]
             return mean, np.sqrt(var)
         import torch
-        q = dev.be.upload(X, torch.float32 if self.predict_dtype == "float32" else torch.float64)
-        mean_d = dev.predict_mean_dev(q, self._y_train_mean, self._y_train_std, self.predict_dtype).double()
+        # fp32 serving is gated (DeviceGP, "fp32 serving gates"): a model whose mean would leave the stated 1e-4
+        # goes through the fp64 kernels, and so do single queries whose fp32 variance is too small a fraction of the
+        # prior's to carry a 1e-3-accurate standard deviation
+        pd = self.predict_dtype
+        gated = pd == "float32" and getattr(self, "fp32_gate", True)
+        vm = self.var_method
+        if gated and not dev.fp32_mean_ok():
+            pd = "float64"
+            vm = "auto" if vm == "inverse_split" else vm      # (the split launch is an fp32 form)
+        q = dev.be.upload(X, torch.float32 if pd == "float32" else torch.float64)
+        mean_d = dev.predict_mean_dev(q, self._y_train_mean, self._y_train_std, pd).double()
         if not return_std:
             mean = mean_d.cpu().numpy()
             return mean[:, 0] if mean.shape[1] == 1 else mean
         comp = self.kernel_.components()
         kss = comp.sf2 + (comp.noise or 0.0)        # kernel_.diag(X): RBF diag + WhiteKernel level
-        var_d = dev.predict_var_dev(q, kss, 0.0, self.predict_dtype, self.var_method)   # clipped at 0 (_gpr.py:479-485)
+        var_d = dev.predict_var_dev(q, kss, 0.0, pd, vm)   # clipped at 0 (_gpr.py:479-485)
+        if gated and pd == "float32":
+            low = torch.nonzero(var_d < dev.FP32_VAR_RECHECK_FRACTION * kss).ravel()
+            if low.numel():
+                q64 = dev.be.upload(X, torch.float64)[low].contiguous()
+                var_d[low] = dev.predict_var_dev(q64, kss, 0.0, "float64",
+                                                 "inverse" if ("f64" in dev._Winv or dev.Np <= dev.INVERSE_EAGER_NP)
+                                                 else "solve")
         both = torch.cat([mean_d, var_d[:, None]], dim=1).cpu().numpy()              # one device->host copy
         mean, var = both[:, :-1], both[:, -1]
         var = np.outer(var, self._y_train_std ** 2)
