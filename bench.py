@@ -194,7 +194,9 @@ def pmc_traffic(kernel_key, N, M):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "RANK" not in os.environ:
+    # (BENCH_FORCE_LAUNCH=1 takes the same parent -> torch.distributed.run -> rank route with one rank: the way to
+    # rehearse the launcher on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("BENCH_FORCE_LAUNCH") == "1") and "RANK" not in os.environ:
         launch_ranks(args)                     # does not return
 
     import torch

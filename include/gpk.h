@@ -270,6 +270,46 @@ int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* 
                  double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
                  double* grad);
 
+/* ---- composite calls: a whole model behind the handle ------------------------------------------------------
+ * For callers that are not Python: the sequencing the Python host side (device.py, gpr.py) otherwise provides,
+ * as thin C++ over the building blocks above.  HOST pointers in and out; the device buffers (X, normalised
+ * targets, factor, leaf inverses, inverse factor, alpha, fp32 serving copies, staging) are owned by the handle, one
+ * model per handle (a new gpk_fit / gpk_import replaces it; gpk_model_release or gpk_destroy frees it).
+ *
+ * gpk_fit: X host (N x D), Y host (N x P) row-major fp64.  ls: n_ls = 1 (isotropic) or D (ARD) length-scales;
+ *   K = sf2 exp(-d^2/2) + (noise + jitter) I (`noise`: the WhiteKernel level, `jitter`: the regressor's alpha).
+ *   normalize_y != 0: targets are centred and divided by their population std per column (a zero std counts as 1).
+ *   Runs K1 -> K2 -> K3 (+ the inverse factor when Np <= 32768) and evaluates the log-marginal likelihood.
+ *   Returns GPK_NOT_PD as gpk_potrf does (the caller decides: sklearn raises, the package GP multiplies its noise by
+ *   10, gaussian_process.py:193-201).  D <= GPK_MAX_D_PREDICT, P <= GPK_MAX_P.
+ *   Replaces: GaussianProcessRegressor.fit at fixed theta, sklearn/gaussian_process/_gpr.py:271-282,343-364, as
+ *   called at src/px4/simple_gp.py:170-177; GaussianProcess.fit, gaussian_process.py:173-201.
+ * gpk_predict: Xq host (M x D), mean host (M x P), var host (M x P: per-output VARIANCE, already multiplied by
+ *   y_std^2; NULL = means only), all of `dtype` (GPK_F64: double buffers, fp64 kernels; GPK_F32: float buffers, the
+ *   fp32 serving kernels - matrix-core mean when admissible, bf16 x 3 split variance).  var_includes_noise != 0:
+ *   k** = sf2 + noise, variance clipped at 0 (scikit-learn: Sum.diag, _gpr.py:474-485; take sqrt for its std);
+ *   == 0: k** = sf2, floored at 1e-10 (gaussian_process.py:229-233).  Queries are processed in panels.
+ *   Replaces: GaussianProcessRegressor.predict, _gpr.py:441-494 (src/px4/simple_gp.py:194, mpc.py:1490-1506);
+ *   GaussianProcess.predict, gaussian_process.py:203-241.
+ * gpk_lml: theta == NULL: *lml = the fitted model's log-marginal likelihood.  Otherwise theta = log [ls (1 or D
+ *   values), noise] (n_theta = 2 or D + 1; sf2 and jitter as fitted): *lml and, if grad != NULL, its gradient with
+ *   respect to theta (same layout; isotropic: summed over the features), evaluated on scratch buffers - the fitted
+ *   factor is not touched.  A non-positive-definite trial matrix gives *lml = -inf, grad = 0 and GPK_OK (what an
+ *   optimiser needs, _gpr.py:586-589).  Replaces: log_marginal_likelihood, _gpr.py:537-652 + kernels.py:1571-1580.
+ * gpk_export / gpk_import: the model as host arrays - L (N x N row-major lower factor, zeros above the diagonal:
+ *   scikit-learn's L_), alpha (N x P), y_mean / y_std (P) - e.g. to write or read the reference's model files
+ *   (src/px4/train_gp_offline.py:188-194; gaussian_process.py:369-394 stores the training set and refits).  NULL
+ *   outputs are skipped.  An imported model predicts; gpk_lml(theta) needs a fitted one.                        */
+int gpk_fit(gpk_handle h, const double* X, int64_t N, int D, const double* Y, int P, const double* ls, int n_ls,
+            double sf2, double noise, double jitter, int normalize_y);
+int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, void* var, int dtype, int var_includes_noise);
+int gpk_lml(gpk_handle h, const double* theta, int n_theta, double* lml, double* grad);
+int gpk_export(gpk_handle h, int64_t* N, int* D, int* P, double* L, double* alpha, double* y_mean, double* y_std,
+               double* lml);
+int gpk_import(gpk_handle h, const double* X, int64_t N, int D, const double* L, const double* alpha, int P,
+               const double* ls, int n_ls, double sf2, double noise, const double* y_mean, const double* y_std);
+int gpk_model_release(gpk_handle h);
+
 /* ---- building block: whole-tile GEMM on the matrix cores ---------------------------------------
  * C[m x n] = alpha * opA(A) * opB(B)^T + beta * C, m and n multiples of 128, k a multiple of 16
  * (fp64) / 32 (fp32).  ta == 0: A stored (m x k) with k contiguous; ta == 1: A stored (k x m).

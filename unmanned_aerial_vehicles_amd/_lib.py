@@ -29,6 +29,12 @@ SIGNATURES = {
     "gpk_set_stream": (_int, [_vp, _vp]),
     "gpk_synchronize": (_int, [_vp]),
     "gpk_padded": (_i64, [_i64]),
+    "gpk_fit": (_int, [_vp, _dp, _i64, _int, _dp, _int, _dp, _int, _dbl, _dbl, _dbl, _int]),
+    "gpk_predict": (_int, [_vp, _vp, _i64, _vp, _vp, _int, _int]),
+    "gpk_lml": (_int, [_vp, _dp, _int, _dp, _dp]),
+    "gpk_export": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), _dp, _dp, _dp, _dp, _dp]),
+    "gpk_import": (_int, [_vp, _dp, _i64, _int, _dp, _dp, _int, _dp, _int, _dbl, _dbl, _dp, _dp]),
+    "gpk_model_release": (_int, [_vp]),
     "gpk_timing": (_int, [_vp, _int]),
     "gpk_kernel_times": (_int, [_vp, _int, _dp, _int, C.POINTER(_int)]),
     "gpk_batch_begin": (_int, [_vp, _int]),

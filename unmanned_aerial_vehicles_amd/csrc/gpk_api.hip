@@ -42,6 +42,7 @@ extern "C" void gpk_destroy(gpk_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  gpk_model_free(h);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_small) (void)hipFree(h->d_small);

@@ -10,8 +10,11 @@
 
 #include "../../include/gpk.h"
 
+struct gpk_model;    // the composite calls' model (gpk_model.hip)
+
 struct gpk_context {
   int device = 0;
+  gpk_model* model = nullptr;        // owned: gpk_fit / gpk_import create it, gpk_destroy / gpk_model_release free it
   hipStream_t stream = nullptr;      // stream kernels are launched on
   hipStream_t own_stream = nullptr;  // created by gpk_create
   bool user_stream = false;
@@ -83,6 +86,7 @@ struct gpk_context {
   } while (0)
 
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
+void gpk_model_free(gpk_handle h);   // gpk_model.hip
 
 // Event brackets of gpk_timing (no-ops unless enabled): record the first event, launch, record the second.
 constexpr int GPK_TIMING_RING = 64;

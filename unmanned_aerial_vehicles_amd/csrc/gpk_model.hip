@@ -1,0 +1,415 @@
+// Composite entry points of the libgpk C ABI: a whole GP model behind the handle - gpk_fit, gpk_predict, gpk_lml,
+// gpk_export, gpk_import, gpk_model_release - for callers that are not Python.  Thin host code over
+// the building blocks (K1 gpk_gram, K2 gpk_potrf, K3 gpk_potrs[_inv], K4 gpk_predict_mean[_mfma], K5
+// gpk_predict_var_inv[_split], K6 gpk_lml_terms / gpk_wtw / gpk_lml_grad): the target normalisation
+// (sklearn/gaussian_process/_gpr.py:271-282), the K1 -> K2 -> K3 sequencing (_gpr.py:343-364), the query panel loop
+// and the optimiser objective (_gpr.py:537-652) that the Python host side (device.py, gpr.py) otherwise provides.
+// Host pointers in, host pointers out; the device buffers are owned by the handle.
+#include <cmath>
+#include <limits>
+
+#include "gpk_internal.h"
+
+struct gpk_model {
+  int64_t N = 0, Np = 0;
+  int D = 0, P = 0, n_ls = 0, normalize_y = 0;
+  double sf2 = 1.0, noise = 0.0, jitter = 0.0, lml = 0.0;
+  double ls[GPK_MAX_D_PREDICT] = {0}, ls_in[GPK_MAX_D_PREDICT] = {0}, center[GPK_MAX_D_PREDICT] = {0};
+  double y_mean[GPK_MAX_P] = {0}, y_std[GPK_MAX_P] = {0};
+  bool fitted = false, mfma_mean_ok = false;
+  // fp64 state
+  double *X = nullptr, *Yn = nullptr, *K = nullptr, *winv = nullptr, *W = nullptr, *alpha = nullptr;
+  bool has_W = false;
+  // fp32 serving copies (built on the first fp32 predict)
+  float *Xf = nullptr, *alphaf = nullptr;
+  void* W3 = nullptr;            // exact bf16 x 3 split of W (gpk_split3)
+  // scratch of gpk_lml: a second factorisation that leaves the fitted one alone
+  double *sK = nullptr, *sW = nullptr, *sKinv = nullptr, *sT = nullptr, *swinv = nullptr, *salpha = nullptr;
+  // query staging
+  void *q = nullptr, *mean = nullptr, *work = nullptr, *work3 = nullptr;
+  double* var = nullptr;
+  size_t q_bytes = 0, mean_bytes = 0, work_bytes = 0, work3_bytes = 0, var_bytes = 0;
+};
+
+namespace {
+
+void free_all(gpk_model* m) {
+  void* ptrs[] = {m->X, m->Yn, m->K, m->winv, m->W, m->alpha, m->Xf, m->alphaf, m->W3, m->sK, m->sW, m->sKinv, m->sT,
+                  m->swinv, m->salpha, m->q, m->mean, m->work, m->work3, m->var};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+}
+
+template <typename T>
+int dev_alloc(gpk_handle h, T** p, size_t count) {
+  GPK_CHECK_HIP(h, hipMalloc((void**)p, count * sizeof(T)));
+  if (h->debug_fill) GPK_CHECK_HIP(h, hipMemsetAsync(*p, 0xFF, count * sizeof(T), h->stream));
+  return GPK_OK;
+}
+
+int grow(gpk_handle h, void** p, size_t* have, size_t need) {
+  if (need <= *have) {
+    if (h->debug_fill && need) GPK_CHECK_HIP(h, hipMemsetAsync(*p, 0xFF, need, h->stream));
+    return GPK_OK;
+  }
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  if (*p) GPK_CHECK_HIP(h, hipFree(*p));
+  *p = nullptr; *have = 0;
+  GPK_CHECK_HIP(h, hipMalloc(p, need));
+  *have = need;
+  if (h->debug_fill) GPK_CHECK_HIP(h, hipMemsetAsync(*p, 0xFF, need, h->stream));
+  return GPK_OK;
+}
+
+__global__ void to_float_kernel(const double* __restrict__ s, long long n, float* __restrict__ d) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] = (float)s[i];
+}
+
+// var_n[m] * y_std[p]^2 -> out[m][p]  (sklearn/_gpr.py:487-489: undo the normalisation of the variance)
+template <typename T>
+__global__ void scale_var_kernel(const double* __restrict__ var, long long M, int P, const double* __restrict__ ystd,
+                                 T* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < M * P) { const double s = ystd[i % P]; out[i] = (T)(var[i / P] * s * s); }
+}
+
+// the fp32 matrix-core mean kernel expands |a - b|^2 around `center`; admissible while the largest scaled squared
+// norm (exp2 units) stays below 64 (device.py MFMA_MEAN_R2_MAX; gpk.h gpk_predict_mean_mfma)
+bool mfma_mean_admissible(const double* X, int64_t N, int D, int P, const double* ls, double* center) {
+  for (int d = 0; d < D; ++d) {
+    double s = 0.0;
+    for (int64_t i = 0; i < N; ++i) s += X[i * D + d];
+    center[d] = s / (double)N;
+  }
+  double r2 = 0.0;
+  for (int64_t i = 0; i < N; ++i) {
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) { const double u = (X[i * D + d] - center[d]) / ls[d]; s += u * u; }
+    if (s > r2) r2 = s;
+  }
+  return P <= 8 && 0.5 * 1.4426950408889634 * r2 <= 64.0;
+}
+
+int set_hyper(gpk_handle h, gpk_model* m, const double* ls, int n_ls, double sf2, double noise, double jitter) {
+  GPK_REQUIRE(h, ls && (n_ls == 1 || n_ls == m->D), "length-scales: n_ls must be 1 (isotropic) or D (ARD)");
+  GPK_REQUIRE(h, sf2 > 0.0 && noise >= 0.0 && jitter >= 0.0, "sf2 must be positive, noise and jitter non-negative");
+  for (int d = 0; d < m->D; ++d) {
+    m->ls[d] = ls[n_ls == 1 ? 0 : d];
+    GPK_REQUIRE(h, m->ls[d] > 0.0 && std::isfinite(m->ls[d]), "length-scales must be positive");
+  }
+  for (int d = 0; d < n_ls; ++d) m->ls_in[d] = ls[d];
+  m->n_ls = n_ls; m->sf2 = sf2; m->noise = noise; m->jitter = jitter;
+  return GPK_OK;
+}
+
+// W = L^-1 (one-off N^3/3 flops) - every later variance call and the alpha solve are then single GEMM launches
+int ensure_W(gpk_handle h, gpk_model* m) {
+  if (m->has_W) return GPK_OK;
+  if (!m->W) GPK_TRY(dev_alloc(h, &m->W, (size_t)m->Np * m->Np));
+  double* T = nullptr;
+  const size_t tsz = (size_t)(m->Np / 2 + 128) * (m->Np / 2 + 128);
+  GPK_CHECK_HIP(h, hipMalloc((void**)&T, tsz * sizeof(double)));
+  int rc = gpk_trtri(h, m->K, m->Np, m->Np, m->winv, m->W, m->Np, T);
+  if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
+  (void)hipFree(T);
+  GPK_TRY(rc);
+  m->has_W = true;
+  if (m->W3) { (void)hipFree(m->W3); m->W3 = nullptr; }
+  return GPK_OK;
+}
+
+int new_model(gpk_handle h, int64_t N, int D, int P, gpk_model** out) {
+  GPK_REQUIRE(h, N >= 1 && D >= 1 && D <= GPK_MAX_D_PREDICT && P >= 1 && P <= GPK_MAX_P,
+              "need N >= 1, 1 <= D <= GPK_MAX_D_PREDICT, 1 <= P <= GPK_MAX_P");
+  GPK_REQUIRE(h, h->batch == 1, "composite calls are not available in batched mode");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->model) { free_all(h->model); delete h->model; h->model = nullptr; }
+  gpk_model* m = new gpk_model();
+  h->model = m;
+  m->N = N; m->Np = gpk_padded(N); m->D = D; m->P = P;
+  GPK_TRY(dev_alloc(h, &m->X, (size_t)N * D));
+  GPK_TRY(dev_alloc(h, &m->Yn, (size_t)N * P));
+  GPK_TRY(dev_alloc(h, &m->alpha, (size_t)N * P));
+  GPK_TRY(dev_alloc(h, &m->K, (size_t)m->Np * m->Np));
+  GPK_TRY(dev_alloc(h, &m->winv, (size_t)m->Np * GPK_TILE));
+  *out = m;
+  return GPK_OK;
+}
+
+// up to this padded size W is formed at fit time (cheap); larger models form it on the first variance request
+constexpr int64_t EAGER_W_NP = 32768;
+
+}  // namespace
+
+void gpk_model_free(gpk_handle h) {
+  if (h->model) { free_all(h->model); delete h->model; h->model = nullptr; }
+}
+
+extern "C" int gpk_model_release(gpk_handle h) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  gpk_model_free(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_fit(gpk_handle h, const double* X, int64_t N, int D, const double* Y, int P, const double* ls,
+                       int n_ls, double sf2, double noise, double jitter, int normalize_y) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && Y, "fit: null pointer");
+  gpk_model* m = nullptr;
+  GPK_TRY(new_model(h, N, D, P, &m));
+  GPK_TRY(set_hyper(h, m, ls, n_ls, sf2, noise, jitter));
+  for (int64_t i = 0; i < N * D; ++i) GPK_REQUIRE(h, std::isfinite(X[i]), "fit: X contains NaN or infinity");
+  // target normalisation: population std, a (numerically) zero std counts as 1   (_gpr.py:271-282)
+  std::vector<double> yn((size_t)N * P);
+  m->normalize_y = normalize_y ? 1 : 0;
+  for (int p = 0; p < P; ++p) {
+    double mean = 0.0, std_ = 1.0;
+    for (int64_t i = 0; i < N; ++i) GPK_REQUIRE(h, std::isfinite(Y[i * P + p]), "fit: Y contains NaN or infinity");
+    if (normalize_y) {
+      for (int64_t i = 0; i < N; ++i) mean += Y[i * P + p];
+      mean /= (double)N;
+      double v = 0.0;
+      for (int64_t i = 0; i < N; ++i) { const double d = Y[i * P + p] - mean; v += d * d; }
+      std_ = std::sqrt(v / (double)N);
+      if (std_ < 10.0 * std::numeric_limits<double>::epsilon()) std_ = 1.0;
+    }
+    m->y_mean[p] = mean; m->y_std[p] = std_;
+    for (int64_t i = 0; i < N; ++i) yn[(size_t)i * P + p] = (Y[i * P + p] - mean) / std_;
+  }
+  m->mfma_mean_ok = mfma_mean_admissible(X, N, D, P, m->ls, m->center);
+  GPK_CHECK_HIP(h, hipMemcpyAsync(m->X, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  GPK_CHECK_HIP(h, hipMemcpyAsync(m->Yn, yn.data(), (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));      // (yn leaves scope)
+  // K1 -> K2 -> K3   (_gpr.py:343-364); a non-positive-definite matrix is reported as GPK_NOT_PD (_gpr.py:350-358)
+  GPK_TRY(gpk_gram(h, GPK_F64, m->X, N, D, m->ls, sf2, noise + jitter, m->K, m->Np));
+  int info = 0;
+  GPK_TRY(gpk_potrf(h, m->K, m->Np, m->Np, m->winv, &info));
+  if (m->Np <= EAGER_W_NP) {
+    GPK_TRY(ensure_W(h, m));
+    GPK_TRY(gpk_potrs_inv(h, m->W, m->Np, m->Np, m->Yn, N, P, m->alpha));
+  } else {
+    GPK_TRY(gpk_potrs(h, m->K, m->Np, m->Np, m->winv, m->Yn, N, P, m->alpha));
+  }
+  double terms[1 + GPK_MAX_P];
+  GPK_TRY(gpk_lml_terms(h, m->K, N, m->Np, m->Yn, m->alpha, P, terms));
+  m->lml = 0.0;
+  for (int p = 0; p < P; ++p) m->lml += -0.5 * terms[1 + p] - terms[0] - 0.5 * (double)N * std::log(2.0 * M_PI);
+  m->fitted = true;
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, void* var, int dtype,
+                           int var_includes_noise) {
+  if (!h) return GPK_BAD_ARG;
+  gpk_model* m = h->model;
+  GPK_REQUIRE(h, m && m->fitted, "predict: no model (call gpk_fit or gpk_import first)");
+  GPK_REQUIRE(h, Xq && mean && M >= 1, "predict: null pointer or empty batch");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "predict: bad dtype");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  const bool f32 = dtype == GPK_F32;
+  const size_t es = f32 ? 4 : 8;
+  const int D = m->D, P = m->P;
+  for (int64_t i = 0; i < M * D; ++i) {
+    const double v = f32 ? (double)((const float*)Xq)[i] : ((const double*)Xq)[i];
+    GPK_REQUIRE(h, std::isfinite(v), "predict: Xq contains NaN or infinity");
+  }
+  // sklearn surface: k** = sf2 + noise (Sum.diag), clipped at 0; package surface: k** = sf2, floored at 1e-10
+  const double kss = m->sf2 + (var_includes_noise ? m->noise : 0.0), floor_ = var_includes_noise ? 0.0 : 1e-10;
+  if (var) GPK_TRY(ensure_W(h, m));
+  // control-loop batches, fp64: the one-call serving path (two launches up to 32 rows)
+  if (!f32 && M <= 64 && (!var || m->Np <= GPK_SMALL_MAX_NP)) {
+    std::vector<double> v1((size_t)M);
+    GPK_TRY(gpk_predict_host(h, m->X, m->alpha, m->N, D, P, m->ls, m->sf2, m->y_mean, m->y_std, var ? m->W : nullptr,
+                             m->Np, m->Np, kss, floor_, (const double*)Xq, M, (double*)mean, var ? v1.data() : nullptr));
+    if (var)
+      for (int64_t i = 0; i < M; ++i)
+        for (int p = 0; p < P; ++p) ((double*)var)[i * P + p] = v1[(size_t)i] * m->y_std[p] * m->y_std[p];
+    return GPK_OK;
+  }
+  if (f32 && !m->Xf) {
+    GPK_TRY(dev_alloc(h, &m->Xf, (size_t)m->N * D));
+    GPK_TRY(dev_alloc(h, &m->alphaf, (size_t)m->N * P));
+    const long long nx = m->N * D, na = m->N * P;
+    hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, h->stream, m->X, nx, m->Xf);
+    hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, m->alpha, na, m->alphaf);
+    GPK_LAUNCH_CHECK(h);
+  }
+  if (f32 && var && !m->W3) {
+    // fp32 serving form of K5: W as three exact bf16 parts per entry (the fp32 copy is only the source of the split)
+    float* Wf = nullptr;
+    GPK_CHECK_HIP(h, hipMalloc((void**)&Wf, (size_t)m->Np * m->Np * sizeof(float)));
+    int rc = gpk_tril_to_f32(h, m->W, m->Np, m->Np, Wf, m->Np);
+    if (rc == GPK_OK) rc = hipMalloc(&m->W3, (size_t)m->Np * m->Np * 6) == hipSuccess ? GPK_OK : GPK_HIP_ERROR;
+    if (rc == GPK_OK) rc = gpk_split3(h, Wf, m->Np, m->Np, m->Np, m->W3);
+    if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
+    (void)hipFree(Wf);
+    GPK_TRY(rc);
+  }
+  // panel loop: <= 16384 queries and <= 4 GiB of K* per panel
+  int64_t panel = (int64_t)((4ull << 30) / ((size_t)m->Np * es)) / GPK_TILE * GPK_TILE;
+  if (panel > 16384) panel = 16384;
+  if (panel < GPK_TILE) panel = GPK_TILE;
+  if (panel > gpk_padded(M)) panel = gpk_padded(M);
+  GPK_TRY(grow(h, &m->q, &m->q_bytes, (size_t)panel * D * es));
+  GPK_TRY(grow(h, &m->mean, &m->mean_bytes, (size_t)panel * P * es));
+  if (var) {
+    GPK_TRY(grow(h, &m->work, &m->work_bytes, (size_t)m->Np * panel * es));
+    if (f32) GPK_TRY(grow(h, &m->work3, &m->work3_bytes, (size_t)m->Np * panel * 6));
+    GPK_TRY(grow(h, (void**)&m->var, &m->var_bytes, (size_t)panel * sizeof(double) + (size_t)panel * P * es + GPK_MAX_P * sizeof(double)));
+  }
+  double* d_ystd = nullptr;
+  void* d_varout = nullptr;
+  if (var) {
+    d_ystd = m->var + panel;
+    d_varout = (void*)(d_ystd + GPK_MAX_P);
+    GPK_CHECK_HIP(h, hipMemcpyAsync(d_ystd, m->y_std, P * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  for (int64_t m0 = 0; m0 < M; m0 += panel) {
+    const int64_t mc = M - m0 < panel ? M - m0 : panel;
+    GPK_CHECK_HIP(h, hipMemcpyAsync(m->q, (const char*)Xq + (size_t)m0 * D * es, (size_t)mc * D * es, hipMemcpyHostToDevice, h->stream));
+    if (f32 && m->mfma_mean_ok)
+      GPK_TRY(gpk_predict_mean_mfma(h, m->Xf, m->alphaf, m->N, D, P, m->ls, m->sf2, m->center, m->y_mean, m->y_std,
+                                    (const float*)m->q, mc, (float*)m->mean));
+    else
+      GPK_TRY(gpk_predict_mean(h, dtype, f32 ? (const void*)m->Xf : (const void*)m->X,
+                               f32 ? (const void*)m->alphaf : (const void*)m->alpha, m->N, D, P, m->ls, m->sf2, m->y_mean,
+                               m->y_std, m->q, mc, m->mean));
+    GPK_CHECK_HIP(h, hipMemcpyAsync((char*)mean + (size_t)m0 * P * es, m->mean, (size_t)mc * P * es, hipMemcpyDeviceToHost, h->stream));
+    if (var) {
+      if (f32)
+        GPK_TRY(gpk_predict_var_inv_split(h, m->Xf, m->N, D, m->ls, m->sf2, m->W3, m->Np, (const float*)m->q, mc, kss,
+                                          floor_, (float*)m->work, m->work3, m->var));
+      else
+        GPK_TRY(gpk_predict_var_inv(h, GPK_F64, m->X, m->N, D, m->ls, m->sf2, m->W, m->Np, m->Np, m->q, mc, kss, floor_,
+                                    m->work, m->var));
+      const long long tot = mc * P;
+      if (f32)
+        hipLaunchKernelGGL(scale_var_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, m->var,
+                           (long long)mc, P, d_ystd, (float*)d_varout);
+      else
+        hipLaunchKernelGGL(scale_var_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, m->var,
+                           (long long)mc, P, d_ystd, (double*)d_varout);
+      GPK_LAUNCH_CHECK(h);
+      GPK_CHECK_HIP(h, hipMemcpyAsync((char*)var + (size_t)m0 * P * es, d_varout, (size_t)mc * P * es, hipMemcpyDeviceToHost, h->stream));
+    }
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));     // the staging blocks are reused by the next panel
+  }
+  return GPK_OK;
+}
+
+extern "C" int gpk_lml(gpk_handle h, const double* theta, int n_theta, double* lml, double* grad) {
+  if (!h) return GPK_BAD_ARG;
+  gpk_model* m = h->model;
+  GPK_REQUIRE(h, m && m->fitted, "lml: no model (call gpk_fit or gpk_import first)");
+  GPK_REQUIRE(h, lml, "lml: null pointer");
+  if (!theta) {                      // the fitted model's own value (_gpr.py:560-563)
+    GPK_REQUIRE(h, !grad, "lml: the gradient needs theta");
+    *lml = m->lml;
+    return GPK_OK;
+  }
+  GPK_REQUIRE(h, m->normalize_y != -1, "lml(theta): an imported model does not carry the training targets");
+  // theta = log [ls (1 value: isotropic, or D values: ARD), noise]; sf2 and jitter stay as fitted
+  GPK_REQUIRE(h, n_theta == 2 || n_theta == m->D + 1, "lml: theta must hold log length-scale(s) and log noise");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  const int nl = n_theta - 1, D = m->D, P = m->P;
+  double ls[GPK_MAX_D_PREDICT];
+  for (int d = 0; d < D; ++d) ls[d] = std::exp(theta[nl == 1 ? 0 : d]);
+  const double noise = std::exp(theta[nl]);
+  const size_t nn = (size_t)m->Np * m->Np;
+  if (!m->sK) {
+    GPK_TRY(dev_alloc(h, &m->sK, nn));
+    GPK_TRY(dev_alloc(h, &m->sW, nn));
+    GPK_TRY(dev_alloc(h, &m->sT, (size_t)(m->Np / 2 + 128) * (m->Np / 2 + 128)));
+    GPK_TRY(dev_alloc(h, &m->swinv, (size_t)m->Np * GPK_TILE));
+    GPK_TRY(dev_alloc(h, &m->salpha, (size_t)m->N * P));
+  }
+  if (grad && !m->sKinv) GPK_TRY(dev_alloc(h, &m->sKinv, nn));
+  GPK_TRY(gpk_gram(h, GPK_F64, m->X, m->N, D, ls, m->sf2, noise + m->jitter, m->sK, m->Np));
+  int info = 0;
+  const int rc = gpk_potrf(h, m->sK, m->Np, m->Np, m->swinv, &info);
+  if (rc == GPK_NOT_PD) {            // inside an optimiser: LML = -inf, zero gradient (_gpr.py:586-589)
+    *lml = -std::numeric_limits<double>::infinity();
+    if (grad) for (int i = 0; i < n_theta; ++i) grad[i] = 0.0;
+    return GPK_OK;
+  }
+  GPK_TRY(rc);
+  GPK_TRY(gpk_trtri(h, m->sK, m->Np, m->Np, m->swinv, m->sW, m->Np, m->sT));
+  GPK_TRY(gpk_potrs_inv(h, m->sW, m->Np, m->Np, m->Yn, m->N, P, m->salpha));
+  double terms[1 + GPK_MAX_P];
+  GPK_TRY(gpk_lml_terms(h, m->sK, m->N, m->Np, m->Yn, m->salpha, P, terms));
+  double v = 0.0;
+  for (int p = 0; p < P; ++p) v += -0.5 * terms[1 + p] - terms[0] - 0.5 * (double)m->N * std::log(2.0 * M_PI);
+  *lml = v;
+  if (grad) {
+    double g[GPK_MAX_D_PREDICT + 2];
+    GPK_TRY(gpk_wtw(h, m->sW, m->Np, m->Np, m->sKinv, m->Np));
+    GPK_TRY(gpk_lml_grad(h, m->X, m->N, D, ls, m->sf2, noise, m->salpha, P, m->sKinv, m->Np, g));
+    if (nl == 1) { double s = 0.0; for (int d = 0; d < D; ++d) s += g[d]; grad[0] = s; }   // kernels.py:1574-1576
+    else for (int d = 0; d < D; ++d) grad[d] = g[d];
+    grad[nl] = g[D];
+  }
+  return GPK_OK;
+}
+
+extern "C" int gpk_export(gpk_handle h, int64_t* N, int* D, int* P, double* L, double* alpha, double* y_mean,
+                          double* y_std, double* lml) {
+  if (!h) return GPK_BAD_ARG;
+  gpk_model* m = h->model;
+  GPK_REQUIRE(h, m && m->fitted, "export: no model");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  if (N) *N = m->N;
+  if (D) *D = m->D;
+  if (P) *P = m->P;
+  if (L) {      // the lower factor, N x N row-major, zeros above the diagonal (what scikit-learn keeps as L_)
+    GPK_CHECK_HIP(h, hipMemcpy2DAsync(L, (size_t)m->N * sizeof(double), m->K, (size_t)m->Np * sizeof(double),
+                                      (size_t)m->N * sizeof(double), (size_t)m->N, hipMemcpyDeviceToHost, h->stream));
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < m->N; ++i)
+      for (int64_t j = i + 1; j < m->N; ++j) L[i * m->N + j] = 0.0;
+  }
+  if (alpha) GPK_CHECK_HIP(h, hipMemcpyAsync(alpha, m->alpha, (size_t)m->N * m->P * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  for (int p = 0; p < m->P; ++p) {
+    if (y_mean) y_mean[p] = m->y_mean[p];
+    if (y_std) y_std[p] = m->y_std[p];
+  }
+  if (lml) *lml = m->lml;
+  return GPK_OK;
+}
+
+extern "C" int gpk_import(gpk_handle h, const double* X, int64_t N, int D, const double* L, const double* alpha, int P,
+                          const double* ls, int n_ls, double sf2, double noise, const double* y_mean, const double* y_std) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && L && alpha && y_mean && y_std, "import: null pointer");
+  gpk_model* m = nullptr;
+  GPK_TRY(new_model(h, N, D, P, &m));
+  GPK_TRY(set_hyper(h, m, ls, n_ls, sf2, noise, 0.0));
+  for (int p = 0; p < P; ++p) { m->y_mean[p] = y_mean[p]; m->y_std[p] = y_std[p]; }
+  m->mfma_mean_ok = mfma_mean_admissible(X, N, D, P, m->ls, m->center);
+  GPK_CHECK_HIP(h, hipMemcpyAsync(m->X, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  GPK_CHECK_HIP(h, hipMemcpyAsync(m->alpha, alpha, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // the padded factor [L 0; 0 I]; Yn is not part of a stored model: Yn = (L L^T) alpha is not needed for prediction
+  // (gpk_lml on an imported model is refused below)
+  GPK_CHECK_HIP(h, hipMemsetAsync(m->K, 0, (size_t)m->Np * m->Np * sizeof(double), h->stream));
+  GPK_CHECK_HIP(h, hipMemcpy2DAsync(m->K, (size_t)m->Np * sizeof(double), L, (size_t)N * sizeof(double),
+                                    (size_t)N * sizeof(double), (size_t)N, hipMemcpyHostToDevice, h->stream));
+  if (m->Np > N) {
+    std::vector<double> ones((size_t)(m->Np - N), 1.0);
+    GPK_CHECK_HIP(h, hipMemcpy2DAsync(m->K + N * m->Np + N, (size_t)(m->Np + 1) * sizeof(double), ones.data(), sizeof(double),
+                                      sizeof(double), (size_t)(m->Np - N), hipMemcpyHostToDevice, h->stream));
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  GPK_TRY(gpk_leaf_inverses(h, m->K, m->Np, m->Np, m->winv));
+  if (m->Np <= EAGER_W_NP) GPK_TRY(ensure_W(h, m));
+  // Yn = K alpha = L (L^T alpha) is recovered lazily only if gpk_lml is asked for: not supported on imported models
+  GPK_CHECK_HIP(h, hipMemsetAsync(m->Yn, 0, (size_t)N * P * sizeof(double), h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  m->lml = std::numeric_limits<double>::quiet_NaN();
+  m->normalize_y = -1;               // unknown: marks an imported model (gpk_lml(theta) needs the training targets)
+  m->fitted = true;
+  return GPK_OK;
+}

@@ -329,7 +329,7 @@ class DeviceGP:
             self._r2 = {key: 0.5 * np.log2(np.e) * float(np.max(np.einsum("ij,ij->i", u, u)))}
         return "mfma" if (self.P <= 8 and self._r2[key] <= self.MFMA_MEAN_R2_MAX) else "valu"
 
-    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64", kernel="auto", _alpha=None):
+    def predict_mean_dev(self, Xq, y_mean, y_std, dtype="float64", kernel="auto", _alpha=None, _kernel=None):
         """K4 on device tensors; returns a (M, P) tensor of `dtype`.  kernel: "valu" (exact differences on
         the vector ALU), "mfma" (fp32 only: distances on the matrix cores) or "auto" (mfma for fp32 when
         `mean_kernel_choice` admits it)."""
@@ -353,6 +353,7 @@ class DeviceGP:
         ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
         ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
         be = self.be
+        ls_, sf2_ = (self.ls, self.sf2) if _kernel is None else (np.ascontiguousarray(_kernel[0]), float(_kernel[1]))
         if kernel == "mfma":
             with be.lock:
                 be.bind_stream()
@@ -364,7 +365,7 @@ class DeviceGP:
         with be.lock:
             be.bind_stream()
             be.check(be.lib.gpk_predict_mean(be.h, GPK_F32 if f32 else GPK_F64, _p(Xd), _p(ad), self.N, self.D,
-                                             self.P, self.ls.ctypes.data_as(_lib._dp), self.sf2,
+                                             self.P, ls_.ctypes.data_as(_lib._dp), sf2_,
                                              ym.ctypes.data_as(_lib._dp), ys.ctypes.data_as(_lib._dp), _p(q), M,
                                              _p(out)))
         return out
@@ -455,22 +456,24 @@ class DeviceGP:
 
     # ---- fp32 serving gates -------------------------------------------------------------------------------------
     # The fp32 predict path is stated as: mean within 1e-4, std within 1e-3 (relative to the largest value) of the
-    # fp64 path.  An fp32 kernel entry carries the rounding of its squared distance (a few 1e-6 relative), so the mean
-    # error is ~5e-6 * sum_j |k*_j alpha_j| / |mean|: fine for the models the reference trains (noise 0.03-0.3), not
-    # for sf2 N / noise ~ 1e7.  `fp32_mean_amplification` measures that ratio on a sample of training rows once per
-    # alpha; the estimator routes a model above FP32_MEAN_AMP_MAX to the fp64 kernels (gpr.py).
-    FP32_MEAN_ERR_PER_AMP = 5e-6
+    # fp64 path.  An fp32 kernel value carries the rounding of its exponent - an ulp of d^2/2 ~ 10 is 1e-6 - so every
+    # term k*_j alpha_j of the mean is off by a few 1e-7 of itself, with random sign: the mean error is
+    # c * sqrt(sum_j (k*_j alpha_j)^2) with c = 2.6e-7 .. 5.6e-7 for the matrix-core kernel and 3.1e-7 .. 8.9e-7 for the
+    # exact-difference kernel (measured over 41 random models, N = 431 .. 65 536, D = 1 .. 16, noise 1e-3 .. 0.3:
+    # tools/exp_fp32_gate.py, profiles/r02_fp32_gate_calibration.log).  Fine for the models the reference trains
+    # (noise 0.03 - 0.3), not for sf2 N / noise ~ 1e7, where alpha is huge and cancels.  `fp32_mean_amplification`
+    # measures A2 = max_m sqrt(sum_j (k_mj alpha_j)^2) / max_m |mean_m| on a sample of training rows (where it is
+    # largest) once per alpha; the estimator routes a model with c * A2 above 1e-4 to the fp64 kernels (gpr.py).
+    FP32_MEAN_ERR_PER_AMP = {"mfma": 5.6e-7, "valu": 9.0e-7}
     FP32_MEAN_TOL = 1e-4
-    FP32_MEAN_AMP_MAX = FP32_MEAN_TOL / FP32_MEAN_ERR_PER_AMP          # = 20
     # Variance: |W k*|^2 in fp32 is off by ~4e-6 kss (measured, N = 10^4 .. 6.5 10^4), i.e. the relative error of the
     # standard deviation is ~2e-6 kss / var: queries whose variance is below this fraction of the prior's are
     # recomputed in fp64 (2.5x margin to the 1e-3 bar).
     FP32_VAR_RECHECK_FRACTION = 5e-3
 
     def fp32_mean_amplification(self):
-        """max over a sample of <= 1024 training rows (as queries) of sum_j |k*_j| |alpha_j| divided by the largest
-        |sum_j k*_j alpha_j| of the sample: how much larger than the posterior mean the sum of the magnitudes of its
-        terms is.  Two fp64 K4 launches, cached per alpha."""
+        """A2 (see above) on <= 1024 evenly spaced training rows: two fp64 K4 launches - the second with the squared
+        kernel (length-scales / sqrt 2, sf2^2) and squared weights - cached per alpha."""
         torch = _torch()
         c = getattr(self, "_amp", None)            # (solve_alpha / set_alpha reset it: the library writes alpha in place)
         if c is not None and c[0] is self.ls:
@@ -479,13 +482,14 @@ class DeviceGP:
         q = self.X[idx].contiguous()
         zeros, ones = np.zeros(self.P), np.ones(self.P)
         b = self.predict_mean_dev(q, zeros, ones, "float64", "valu").abs().amax(dim=0)
-        a = self.predict_mean_dev(q, zeros, ones, "float64", "valu", _alpha=self.alpha.abs()).amax(dim=0)
-        amp = float((a / b.clamp_min(1e-300)).max())
+        a2 = self.predict_mean_dev(q, zeros, ones, "float64", "valu", _alpha=self.alpha ** 2,
+                                   _kernel=(self.ls / np.sqrt(2.0), self.sf2 ** 2)).amax(dim=0).sqrt()
+        amp = float((a2 / b.clamp_min(1e-300)).max())
         self._amp = (self.ls, amp)
         return amp
 
     def fp32_mean_ok(self):
-        return self.fp32_mean_amplification() <= self.FP32_MEAN_AMP_MAX
+        return self.FP32_MEAN_ERR_PER_AMP[self.mean_kernel_choice()] * self.fp32_mean_amplification() <= self.FP32_MEAN_TOL
 
     def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64", method="auto"):
         """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units).

@@ -24,13 +24,23 @@ OUTPUT_NAMES = ["x_residual", "y_residual", "z_residual", "vx_residual", "vy_res
 
 
 class StandardScaler:
-    """z-scoring with population std; zero scale -> 1 (what the reference gets from scikit-learn)."""
+    """z-scoring with the population variance, as the reference gets it from scikit-learn 1.7.2
+    (`gp_trainer.py:152-156` -> `sklearn/preprocessing/_data.py` StandardScaler.partial_fit): the variance is the
+    corrected two-pass form of `_incremental_mean_and_var`, and a feature counts as constant (scale 1) when its variance
+    is not above `n eps var + (n mean eps)^2` (`_is_constant_feature`) - NOT when its std is below 10 eps: the yaw-rate
+    column of the flight CSVs has a std of 1e-21 and is scaled to unit variance like every other column."""
 
     def fit(self, A):
         A = np.asarray(A, dtype=np.float64)
-        self.mean_ = A.mean(axis=0)
-        s = A.std(axis=0)
-        self.scale_ = np.where(s < 10 * np.finfo(np.float64).eps, 1.0, s)
+        n = A.shape[0]
+        self.mean_ = A.sum(axis=0) / n
+        temp = A - self.mean_
+        correction = temp.sum(axis=0)
+        self.var_ = ((temp ** 2).sum(axis=0) - correction ** 2 / n) / n
+        eps = np.finfo(np.float64).eps
+        constant = self.var_ <= n * eps * self.var_ + (n * self.mean_ * eps) ** 2
+        scale = np.sqrt(self.var_)
+        self.scale_ = np.where(constant | (scale == 0.0), 1.0, scale)
         return self
 
     def transform(self, A):
