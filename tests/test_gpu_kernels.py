@@ -373,13 +373,17 @@ def test_split3_is_exact(be):
     assert np.all(x1 <= x0 * 2.0 ** -8 + 1e-45) and np.all(x2 <= x0 * 2.0 ** -16 + 1e-45)
 
 
-@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130)])
-def test_variance_bf16_split_path(be, N, M):
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000)])
+def test_variance_bf16_split_path(be, N, M, form):
     """K5 with the exact bf16x3 operand split (six bf16 MFMAs per fp32 block product) against the fp64 path and
     the fp32-MFMA path on the same queries: the same fp32 accuracy class (std within 1e-3 of fp64 - the stated
     fp32 tolerance - and within 2x of the fp32-MFMA path's own error), in super-tile mode (N = 5000: 40 x 2 tiles
-    is direct; N = 3000 x 700: 24 x 6) and with ragged sizes."""
+    is direct; N = 3000 x 700: 24 x 6) and with ragged sizes.  Both forms of the launch (gpk_set_option
+    "k5_split_form": 32x32x16 MFMAs with register staging / 16x16x32 fused-term MFMAs with LDS filled by DMA; the second
+    serves padded sizes that are multiples of 256 - N = 2500 pads to 2560 - and falls back to the first otherwise)."""
     from unmanned_aerial_vehicles_amd.device import DeviceGP
+    be.check(be.lib.gpk_set_option(be.h, b"k5_split_form", form))
     rng = np.random.default_rng(N)
     X = rng.standard_normal((N, 9))
     Y = np.sin(X @ rng.standard_normal((9, 2))) + 0.1 * rng.standard_normal((N, 2))
@@ -392,6 +396,7 @@ def test_variance_bf16_split_path(be, N, M):
     vsp = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split").cpu().numpy()
     e32 = np.max(np.abs(np.sqrt(v32) - np.sqrt(v64)) / np.sqrt(v64))
     esp = np.max(np.abs(np.sqrt(vsp) - np.sqrt(v64)) / np.sqrt(v64))
+    be.check(be.lib.gpk_set_option(be.h, b"k5_split_form", 1))
     assert esp < 1e-3 and esp < 2.0 * e32 + 1e-6, (e32, esp)
     with pytest.raises(ValueError):
         dev.predict_var_dev(Xq, 1.05, 0.0, "float64", "inverse_split")

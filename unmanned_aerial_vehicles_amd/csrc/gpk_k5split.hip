@@ -310,6 +310,202 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   }
 }
 
+
+// ---- second form of the same launch: 16 x 16 x 32 MFMAs, two product terms per instruction, LDS filled by DMA --------
+// The six products of a block pair up into three v_mfma_f32_16x16x32_bf16: the instruction's k = 32 is used as
+// [k16 of one part | k16 of another part], with the B operand carrying the complementary parts -
+//     (a0 b1 + a1 b0):  A = [a0 | a1], B = [b1 | b0]      (a0 b2 + a2 b0):  A = [a0 | a2], B = [b2 | b0]
+//     (a0 b0 + a1 b1):  A = [a0 | a1], B = [b0 | b1]
+// (lane l of a fragment holds row l & 15 and the eight k of k-group l >> 4: groups 0, 1 = the two halves of the first
+// part's k16, groups 2, 3 = those of the second part).  Same exact products, same fp32 accumulation, smallest terms
+// first; 3 x 16 cycles per 16 x 16 block and k16 = the 6 x 32 cycles per 32 x 32 block of the first form, but the
+// 16 x 16 x 32 shape holds a higher clock under this load (MI355X_MICROARCH.md, DVFS item 7).  Two A fragment
+// types and three B types per block: 20 ds_read_b128 per wave and k-tile (64 x 64 per wave) instead of 12.
+// With 96-byte LDS rows in the global chunk order ([row][half][part]) every one of those reads is conflict-free
+// (checked exhaustively over the four lane groups of ds_read_b128), so the LDS image of a k-tile IS the global
+// image of its row quads: the stage is filled by buffer_load_dwordx4 ... lds (1 KiB per wave instruction, no
+// registers, no ds_write), 36 of them per 256 x 128 tile and k-tile, into a ring of four 36 KiB stages with three
+// k-tiles in flight across the one barrier per k-tile.
+constexpr int V2_TM = 256, V2_TN = 128;
+constexpr int V2_STAGE = (V2_TM + V2_TN) * 96;      // 36864 bytes: [A k-tile | B k-tile]
+constexpr int V2_BOFF = V2_TM * 96;
+constexpr int V2_NSTG = 4;
+constexpr int V2_NDMA = V2_STAGE / 1024;            // 36 wave instructions per stage: 24 of A, 12 of B
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__global__ __launch_bounds__(512, 2) void k5_split16_kernel(SParams p) {
+  __shared__ __attribute__((aligned(1024))) char lds[V2_NSTG * V2_STAGE];
+  constexpr int GSZ = 32, BH = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile mapping (as k5_split_kernel<4>): bands of 1024 rows, groups of 32 tiles, serpentine over XCDs, heavy first
+  const int ntm = p.ntm / 2;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int grp = j / GSZ, slot = j - grp * GSZ;
+  const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
+  if (st >= p.nst) return;
+  const int per = BH * p.ntn, nfull = ntm / BH, hlast = ntm - nfull * BH, total = ntm * p.ntn;
+  const int t = st * GSZ + slot;
+  if (t >= total) return;
+  int tm, tn;
+  {
+    const int band = min(t / per, nfull);
+    const int idx = t - band * per, hh = band < nfull ? BH : hlast;
+    tn = idx / hh;
+    tm = band * BH + (idx - tn * hh);
+  }
+  const int band0 = min(st * GSZ / per, nfull), band1 = min(min(st * GSZ + GSZ - 1, total - 1) / per, nfull);
+  tm = ntm - 1 - tm;
+  const int rhi = (band1 - band0 <= 1) ? ntm - 1 - band0 * BH : tm;
+  const int nkt = (rhi + 1) * (V2_TM / 16);        // k-tiles of 16: at least 16
+  const int row0 = tm * V2_TM, col0 = tn * V2_TN;
+
+  // ---- DMA plan: wave instruction i = wave + 8 q (q = 0 .. 4) of the stage copies 64 consecutive 16-byte chunks;
+  // chunk c of an operand's k-tile lives at quad (c / 24) * rs + (c % 24) * 16 in global memory and at c * 16 in LDS
+  unsigned dvoff[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int i = wave + 8 * q;                                   // wave-uniform
+    const int c = ((i < 24 ? i : i - 24) * 64 + lane);
+    const int quad = c / 24, within = c - quad * 24;
+    dvoff[q] = (unsigned)((long long)quad * (i < 24 ? p.rsa : p.rsb) + within * 16);
+  }
+  // (instructions 32 .. 35 belong to waves 0 .. 3; waves 4 .. 7 repeat them - same source, same destination, same
+  // bytes - so that every wave issues five per k-tile and the loop needs no branch: q = 4 maps wave w to i = 32 + (w & 3))
+  {
+    const int i = 32 + (wave & 3);
+    const int c = (i - 24) * 64 + lane;
+    const int quad = c / 24, within = c - quad * 24;
+    dvoff[4] = (unsigned)((long long)quad * p.rsb + within * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.A + (long long)(row0 >> 2) * p.rsa), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.B + (long long)(col0 >> 2) * p.rsb), 0, 0x7fffffff, 0x00020000);
+  // k-tiles beyond the tile's range are clamped to the last one: a redundant copy into a stage nobody reads any more
+  // keeps the loop free of branches and the vmcnt bookkeeping uniform (five DMAs per wave and k-tile, always)
+  auto dma = [&](int kt) {
+    char* stg = lds + (kt & (V2_NSTG - 1)) * V2_STAGE;
+    const int so = min(kt, nkt - 1) * ROWB;                       // k-tile kt of every quad: + 384 bytes per k-tile
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stg + wave * 1024), 16, dvoff[0], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stg + 8192 + wave * 1024), 16, dvoff[1], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stg + 16384 + wave * 1024), 16, dvoff[2], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(stg + 24576 + wave * 1024), 16, dvoff[3], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(stg + 32768 + (wave & 3) * 1024), 16, dvoff[4], so, 0, 0);
+  };
+
+  // ---- fragment addresses: row r = lane & 15, k-group g = lane >> 4 -> chunk (half g & 1, part s(g))
+  const int fr = lane & 15, g = lane >> 4, fh = g & 1, hi = g >> 1;
+  const int o01 = fr * 96 + (fh * 3 + (hi ? 1 : 0)) * 16;        // [part 0 | part 1]
+  const int o02 = fr * 96 + (fh * 3 + (hi ? 2 : 0)) * 16;        // [part 0 | part 2]
+  const int o10 = fr * 96 + (fh * 3 + (hi ? 0 : 1)) * 16;        // [part 1 | part 0]
+  const int o20 = fr * 96 + (fh * 3 + (hi ? 0 : 2)) * 16;        // [part 2 | part 0]
+  const int abase = wm * 64 * 96, bbase = V2_BOFF + wn * 64 * 96;
+  auto ld = [&](const char* q) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(q)); };
+
+  f4v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 AX[4], AY[4];                  // A fragments of the current k-tile, one row block each: [a0|a1], [a0|a2]
+  bf16x8 BU[2][4], BV[2][4], BZ[2][4];  // B fragments, current and next k-tile: [b1|b0], [b2|b0], [b0|b1]
+
+  dma(0);
+  dma(1);
+  dma(2);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // k-tile 0 has landed (this wave's part)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const char* q = lds + bbase + b * 16 * 96;
+    BU[0][b] = ld(q + o10); BV[0][b] = ld(q + o20); BZ[0][b] = ld(q + o01);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const char* q = lds + abase + a * 16 * 96;
+    AX[a] = ld(q + o01); AY[a] = ld(q + o02);
+  }
+
+#ifndef GPK_K5S2_SCHED
+#define GPK_K5S2_SCHED 1
+#endif
+  auto body = [&](int kt, auto curc) {
+    constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+    // k-tile kt+1 must be complete in LDS for every wave before anybody reads it; k-tile kt+2 stays in flight
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma(kt + 3);                        // into the stage whose fragments were read two barriers ago
+    const char* nb = lds + ((kt + 1) & (V2_NSTG - 1)) * V2_STAGE;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      // the next k-tile's B fragments of column block a, read while this row block multiplies
+      {
+        const char* q = nb + bbase + a * 16 * 96;
+        BU[nxt][a] = ld(q + o10); BV[nxt][a] = ld(q + o20); BZ[nxt][a] = ld(q + o01);
+      }
+      // smallest terms first: (a0 b2 + a2 b0), (a0 b1 + a1 b0), (a0 b0 + a1 b1)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AY[a], BV[cur][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AX[a], BU[cur][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AX[a], BZ[cur][b], acc[a][b], 0, 0, 0);
+      // this row block's A fragments of the next k-tile replace the ones just used
+      {
+        const char* q = nb + abase + a * 16 * 96;
+        AX[a] = ld(q + o01); AY[a] = ld(q + o02);
+      }
+    }
+#if GPK_K5S2_SCHED
+    // issue order: the 20 fragment reads of the next k-tile and the five DMAs spread evenly under the first 40 of the 48
+    // MFMAs (left alone, the scheduler puts all the reads behind the last MFMA: every wave then hits LDS at once and
+    // the next k-tile starts with a wait)
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#endif
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {   // nkt is a multiple of 16
+    body(kt, IntC<0>{});
+    body(kt + 1, IntC<1>{});
+  }
+
+  // ---- epilogue: per-column sums of squares of the tile (fp64), out[tile row][column]
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the clamped tail DMAs and the last fragment reads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  double* red = reinterpret_cast<double*>(lds);      // [4][128]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float v = p.alpha * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[wm * 128 + wn * 64 + b * 16 + lane] = (double)s;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    double t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t2 += red[w * 128 + tid];
+    p.out[(long long)tm * p.Mp + col0 + tid] = t2;
+  }
+}
+
 }  // namespace
 
 extern "C" int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst) {
@@ -354,7 +550,8 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   p.alpha = 1.0f;
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
   gpk_time_begin(h, GPK_TIMED_K5);
-  if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  if (wr == 4 && h->k5_split_form == 2) hipLaunchKernelGGL(k5_split16_kernel, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  else if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
   else hipLaunchKernelGGL(k5_split_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
   gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);
