@@ -354,6 +354,7 @@ def main():
     # rank 0's own shard of the last step against the fp64 kernels on the same batch: the stated fp32 bars
     # (mean 1e-4, std 1e-3, relative) at the headline shape itself
     parity = None
+    v64 = None
     if rank == 0:
         mine = out[:M].double() if use_dist else out.double()
         m64 = dev.predict_mean_dev(q32.double(), y_mean, y_std, "float64")
@@ -476,9 +477,36 @@ def main():
                 "ms_per_step": t32 * 1e3, "predictions_per_s": M / t32,
                 "fp32_mfma_TFLOPs": float(N) * N * M / t32 / 1e12, "frac_of_fp32_mfma_peak": float(N) * N * M / t32 / 1e12 / MFMA_F32_PEAK_TF,
                 "max_abs_var_diff_vs_timed_path": float(torch.max(torch.abs(v32 * float(y_std[0] ** 2) - out[:M, P].double())))}}
+            # the optional fp16 x 2 split (three products per block instead of six; 22-bit products): never the headline
+            dev.split2_inverse_factor()
             dev._Winv.pop("f32", None)
+            dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split2")
+            torch.cuda.synchronize()
+            dev.timing(True)
+            ts = []
+            for _ in range(3):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                dev.predict_mean_dev(q32, y_mean, y_std, "float32")
+                v2 = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split2")
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e-3)
+            k2 = dev.kernel_times(_lib.GPK_TIMED_K5)
+            dev.timing(False)
+            t2 = sorted(ts)[1]
+            extras["fp16x2_split_path"] = {
+                "what": "mean + variance with the variance GEMM on v_mfma_f32_32x32x16_f16: fp32 operands as 2 fp16 parts "
+                        "(22 significant bits), products a1 b0 + a0 b1 + a0 b0, fp32 accumulation (--var-method would be "
+                        "'inverse_split2'; optional fast form, not selected by 'auto')",
+                "ms_per_step": t2 * 1e3, "predictions_per_s": M / t2, "kernel_ms": float(np.mean(k2)),
+                "fp16_mfma_TFLOPs": 3.0 * float(N) * N * M / (float(np.mean(k2)) * 1e-3) / 1e12,
+                "std_max_rel_err_vs_fp64": float(((torch.sqrt(v2) - torch.sqrt(v64)).abs() / torch.sqrt(v64)).max())
+                                           if v64 is not None else None,
+                "std_max_rel_err_vs_fp64_of_the_timed_path": parity["std_max_rel_err_vs_fp64"] if parity else None}
+            dev._Winv.pop("split2", None)
         except Exception as e:  # noqa: BLE001 - an extra must never take the headline down
-            extras = {"error": repr(e)}
+            extras = {"error": repr(e)} if extras is None else dict(extras, error=repr(e))
 
     if rank == 0:
         total_pred = float(M) * world * args.steps

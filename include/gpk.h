@@ -210,6 +210,22 @@ int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, co
                               const void* W3, int64_t Np, const float* Xq, int64_t M, double kss, double floor_,
                               float* work, void* work3, double* var);
 
+/* Optional fast form of the same launch at slightly less than fp32 accuracy: fp16 x 2 split, three products per block.
+ * gpk_split2: src (dev rows x ld fp32) -> dst (dev, rows * cols * 4 bytes): x * scale = h0 + h1 (+ a remainder below
+ * 2^-22 |x|) with h0, h1 fp16, chunk order [row / 4][k16 block][row % 4][half][part]; `scale` is a power of two chosen
+ * by the caller so that max |x * scale| <= 2^15 (it puts the operand at the top of fp16's range; entries more than
+ * 2^-12 below the largest lose relative - not absolute - precision).
+ * gpk_predict_var_inv_split2: as gpk_predict_var_inv_split with W2 = gpk_split2(fp32 inverse factor, w_scale); K* is
+ * scaled by the power of two below 2^15 / sf2 internally; block products are a1 b0 + a0 b1 + a0 b0 on
+ * v_mfma_f32_32x32x16_f16 (22 significant bits per product instead of 24, fp32 accumulation): half the matrix-pipe work of
+ * the exact split.  Not the default anywhere: for callers (e.g. an MPC confidence gate) to whom a 1e-4 relative error
+ * of the standard deviation is immaterial.  work: dev float[Mp * Np]; work2: dev, Mp * Np * 4 bytes; var: dev double[Mp].
+ * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485).                  */
+int gpk_split2(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, double scale, void* dst);
+int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+                               const void* W2, double w_scale, int64_t Np, const float* Xq, int64_t M, double kss,
+                               double floor_, float* work, void* work2, double* var);
+
 /* K4 for B (<= 8) independent single-output ARD models that share X (the per-axis GPs of
  * src/px4/gp_trainer.py:139-179, predicted one by one at src/px4/pretrained_gp.py:64-91): one launch
  * evaluates every model; the feature differences of a (query, training point) pair are formed once.

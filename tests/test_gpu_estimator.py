@@ -404,6 +404,10 @@ def test_baseline_size_properties():
     alpha = dev.alpha_host()
     assert np.max(np.abs(mean - (Yn[idx] - s * alpha[idx]))) < 1e-8
     W = dev.inverse_factor(False)
+    # K3 through W at this size is two streaming passes over W (gpk_potrs_inv, P <= 6): same alpha as the solve chain
+    a_chain = dev.alpha.clone()
+    dev.solve_alpha("inverse")
+    assert float((dev.alpha - a_chain).abs().max() / a_chain.abs().max()) < 1e-10
     for j in (0, 5000, 40000):
         col = dev.K[:N, j].clone()
         col[:j] = 0.0                                   # column j of L (lower triangle)

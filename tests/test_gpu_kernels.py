@@ -203,6 +203,38 @@ def test_potrf_potrs_against_oracle(be, csv_data, N):
     assert relerr(quad, np.einsum("ik,ik->k", st.Yn, st.alpha)) < 1e-10
 
 
+@pytest.mark.parametrize("N,P", [(9000, 3), (8200, 6), (8192, 1), (9100, 4)])
+def test_potrs_inv_streaming_form(be, N, P):
+    """K3 through the inverse factor, large-N form (two streaming matrix-vector passes over W, P <= 6, Np >= 8192)
+    against the two-GEMM form of the same entry point and against the solve chain with L; ragged N, every P class."""
+    import torch
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(N + P)
+    X = rng.standard_normal((N, 5))
+    Y = rng.standard_normal((N, P))
+    dev = DeviceGP(X, Y, be)
+    dev.factorize(1.3, 1.0, 0.2)
+    dev.solve_alpha("chain")
+    a_chain = dev.alpha.clone()
+    dev.inverse_factor(False)
+    dev.alpha.fill_(float("nan"))
+    dev.solve_alpha("inverse")                                   # streaming passes
+    a_stream = dev.alpha.clone()
+    be.check(be.lib.gpk_set_option(be.h, b"k3_stream_min_np", 1 << 30))
+    try:
+        dev.alpha.fill_(float("nan"))
+        dev.solve_alpha("inverse")                               # two tile-GEMM launches
+        a_gemm = dev.alpha.clone()
+    finally:
+        be.check(be.lib.gpk_set_option(be.h, b"k3_stream_min_np", 8192))
+    scale = float(a_chain.abs().max())
+    assert bool(torch.isfinite(a_stream).all())
+    assert float((a_stream - a_gemm).abs().max()) < 1e-12 * scale
+    assert float((a_stream - a_chain).abs().max()) < 1e-10 * scale
+    dev.solve_alpha("inverse")
+    assert torch.equal(dev.alpha, a_stream)                      # fixed reduction order: bit-reproducible
+
+
 def test_potrf_not_positive_definite(be):
     import torch
     from unmanned_aerial_vehicles_amd._lib import NotPositiveDefinite
@@ -398,6 +430,14 @@ def test_variance_bf16_split_path(be, N, M, form):
     esp = np.max(np.abs(np.sqrt(vsp) - np.sqrt(v64)) / np.sqrt(v64))
     be.check(be.lib.gpk_set_option(be.h, b"k5_split_form", 1))
     assert esp < 1e-3 and esp < 2.0 * e32 + 1e-6, (e32, esp)
+    if form == 1:
+        # the optional fp16 x 2 form (three products per block, 22-bit products): inside the stated fp32 tolerance,
+        # within an order of magnitude of the exact paths' error
+        vs2 = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
+        es2 = np.max(np.abs(np.sqrt(vs2) - np.sqrt(v64)) / np.sqrt(v64))
+        assert es2 < 1e-3 and es2 < 16.0 * e32 + 1e-6, (e32, es2)
+        w2, sc = dev.split2_inverse_factor()
+        assert sc == 2.0 ** round(np.log2(sc)) and 16384.0 < sc * float(np.abs(np.tril(dev.inverse_factor(True).cpu().numpy())).max()) <= 32768.0
     with pytest.raises(ValueError):
         dev.predict_var_dev(Xq, 1.05, 0.0, "float64", "inverse_split")
 

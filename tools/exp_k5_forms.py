@@ -25,6 +25,12 @@ dev.split_inverse_factor()
 q = torch.as_tensor(np.random.default_rng(1).standard_normal((M, 9)), dtype=torch.float32, device=be.device)
 v64 = dev.predict_var_dev(q.double(), 1.1, 0.0, "float64", "inverse")
 dev._Winv.pop("f64", None)
+if os.environ.get("ZERO") == "1":
+    # diagnostic: all-zero operands (results are meaningless): W3 zeroed, and length-scales so short that every k* underflows
+    # to 0 - the same instruction stream on data that toggles no bits.  A large speed-up means the launch is limited by
+    # power (the clock the chip holds under this load), not by its instruction schedule.
+    dev._Winv["split"].zero_()
+    dev.ls = np.full(9, 1e-3)
 res = {}
 for form in [int(f) for f in os.environ.get("FORMS", "1,2,1,2").split(",")]:
     be.check(be.lib.gpk_set_option(be.h, b"k5_split_form", form))
@@ -39,6 +45,19 @@ for form in [int(f) for f in os.environ.get("FORMS", "1,2,1,2").split(",")]:
     print(f"form {form}: kernel {np.mean(ms):8.2f} ms (min {np.min(ms):.2f} max {np.max(ms):.2f}) = "
           f"{6.0 * N * N * M / np.mean(ms) / 1e9:7.1f} TF bf16, {M / np.mean(ms) * 1e3 / 1e3:6.1f} k pred/s kernel-only; "
           f"std err vs fp64 {err:.2e}", flush=True)
+if os.environ.get("SPLIT2", "1") == "1" and os.environ.get("ZERO") != "1":
+    dev.split2_inverse_factor()
+    dev._Winv.pop("split", None)
+    dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
+    dev.timing(True)
+    for _ in range(reps):
+        v2 = dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
+    ms = dev.kernel_times(_lib.GPK_TIMED_K5)
+    dev.timing(False)
+    err = float(((v2.sqrt() - v64.sqrt()).abs() / v64.sqrt()).max())
+    print(f"fp16x2 split: kernel {np.mean(ms):8.2f} ms (min {np.min(ms):.2f} max {np.max(ms):.2f}) = "
+          f"{3.0 * N * N * M / np.mean(ms) / 1e9:7.1f} TF fp16, {M / np.mean(ms):6.1f} k pred/s kernel-only; "
+          f"std err vs fp64 {err:.2e}; scale {dev._Winv['split2'][1]:g}", flush=True)
 if 1 in res and 2 in res:
     print("max |form1 - form2| =", float((res[1][0] - res[2][0]).abs().max()), " repeatable:",
           all(torch.equal(a, res[f][0]) for f in res for a in res[f]))

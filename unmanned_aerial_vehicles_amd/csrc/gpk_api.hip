@@ -82,6 +82,7 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "trsm256") h->trsm256 = value;
   else if (n == "trtri_levels") h->trtri_levels = value;
   else if (n == "gemm_small_tiles") h->gemm_small_tiles = value;
+  else if (n == "k3_stream_min_np") h->k3_stream_min_np = value;
   else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
   return GPK_OK;
 }

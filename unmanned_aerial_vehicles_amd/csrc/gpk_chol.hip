@@ -426,6 +426,142 @@ __global__ __launch_bounds__(256) void trsm256_kernel(double* __restrict__ B0, l
       for (int r = 0; r < 4; ++r) B[(long long)(16 * rb + kq + 4 * r) * ldb + NB + c0 + 16 * cb + i] = acc[rb][cb][r];
 }
 
+// ---- K3 at large N: alpha = W^T (W Y) with a handful of right-hand sides, as two streaming passes over W ------
+// With P <= 6 targets the GEMM form of gpk_potrs_inv pads the right-hand sides to a 128-column panel and runs W
+// through 128 x 128 MFMA tiles: 2 x 17 GB at 1.8 TB/s at N = 65 536.  The work is a matrix-vector product per target:
+// bound by reading W once per pass.  These kernels stream the lower triangle as 1 KiB row segments (one wave
+// instruction = 128 consecutive doubles of one row, 8 or 16 of them in flight per wave) and keep the right-hand sides in
+// registers; every reduction runs in a fixed order (bit-reproducible, no atomics).
+//   pass 1  Z = W Y:      a workgroup owns RB rows, its 4 waves take the 128-column chunks c = wave, wave + 4, ...;
+//                         a lane keeps y of its two columns (2 P doubles) and RB x P partial sums, reduced over the
+//                         lanes and waves once per row block
+//   pass 2  alpha = W^T Z: a workgroup owns (128-column chunk, segment of SEG rows); a wave reads whole row segments
+//                         (rows wave, wave + 4, ...), z_i is wave-uniform; partial column sums per segment, then a
+//                         reduction over the segments
+constexpr int K3_SEG = 2048;
+template <int P, int RB>
+__global__ __launch_bounds__(256) void k3_wy_kernel(const double* __restrict__ W, long long ldw, const double* __restrict__ Y,
+                                                    long long N, double* __restrict__ Z, int nblk) {
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  __shared__ double red[4][RB * P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = nblk - 1 - (int)blockIdx.x;                  // heavy first: the longest rows start first
+  const long long r0 = (long long)rb * RB;
+  const int nch = (int)((r0 + RB - 1) / 128) + 1;             // 128-column chunks that reach this row block
+  double acc[RB][P];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[r][p] = 0.0;
+  for (int c = wave; c < nch; c += 4) {
+    const long long j = (long long)c * 128 + 2 * lane;
+    double y0[P], y1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      y0[p] = j < N ? Y[j * P + p] : 0.0;
+      y1[p] = j + 1 < N ? Y[(j + 1) * P + p] : 0.0;
+    }
+    dv2 w[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) w[r] = *reinterpret_cast<const dv2*>(W + (r0 + r) * ldw + j);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      // (entries right of the diagonal are not part of W: they exist only inside the diagonal chunk)
+      const double wx = j <= r0 + r ? w[r].x : 0.0, wy = j + 1 <= r0 + r ? w[r].y : 0.0;
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc[r][p] = __builtin_fma(wy, y1[p], __builtin_fma(wx, y0[p], acc[r][p]));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      double v = acc[r][p];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) red[wave][r * P + p] = v;
+    }
+  __syncthreads();
+  if (tid < RB * P) Z[r0 * P + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k3_wtz_kernel(const double* __restrict__ W, long long ldw, long long Np,
+                                                     const double* __restrict__ Z, double* __restrict__ part, int nseg) {
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  __shared__ double red[4][128 * P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // item -> (column chunk c, row segment s >= first segment that reaches the chunk); enumerated chunk-major, the
+  // chunks with the most segments first
+  const int c = (int)blockIdx.y, s = (int)blockIdx.x;
+  const long long j0 = (long long)c * 128, i_lo = (long long)s * K3_SEG, i_hi = min(Np, i_lo + K3_SEG);
+  if (i_hi <= j0) return;                                     // the segment lies above the chunk's diagonal
+  const long long j = j0 + 2 * lane;
+  double a0[P], a1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) a0[p] = a1[p] = 0.0;
+  const long long ib = max(i_lo, j0);
+  constexpr int U = 8;
+  for (long long i = ib + wave; i < i_hi; i += 4 * U) {
+    dv2 w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long ii = i + 4 * u;
+      w[u] = ii < i_hi ? *reinterpret_cast<const dv2*>(W + ii * ldw + j) : dv2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long ii = __builtin_amdgcn_readfirstlane((int)min(i + 4 * u, i_hi - 1));   // wave-uniform row
+      const double wx = j <= i + 4 * u ? w[u].x : 0.0, wy = j + 1 <= i + 4 * u ? w[u].y : 0.0;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const double z = Z[ii * P + p];
+        a0[p] = __builtin_fma(wx, z, a0[p]);
+        a1[p] = __builtin_fma(wy, z, a1[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    red[wave][(2 * lane) * P + p] = a0[p];
+    red[wave][(2 * lane + 1) * P + p] = a1[p];
+  }
+  __syncthreads();
+  for (int e = tid; e < 128 * P; e += 256)
+    part[((long long)s * Np + j0) * P + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+template <int P>
+__global__ void k3_reduce_kernel(const double* __restrict__ part, long long Np, long long N, int nseg,
+                                 double* __restrict__ alpha) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * P) return;
+  const long long jcol = e / P;
+  double v = 0.0;
+  for (int s = (int)((jcol / 128 * 128) / K3_SEG); s < nseg; ++s) v += part[(long long)s * Np * P + e];
+  alpha[e] = v;
+}
+
+template <int P>
+int k3_stream(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const double* Y, int64_t N, double* alpha) {
+  constexpr int RB = P <= 3 ? 16 : 8;
+  const int nseg = (int)((Np + K3_SEG - 1) / K3_SEG);
+  void* ws = nullptr;
+  GPK_TRY(gpk_scratch(h, ((size_t)Np * P + (size_t)nseg * Np * P) * sizeof(double), &ws));
+  double* Z = (double*)ws;
+  double* part = Z + Np * P;
+  const int nblk = (int)(Np / RB);
+  hipLaunchKernelGGL((k3_wy_kernel<P, RB>), dim3((unsigned)nblk), dim3(256), 0, h->stream, W, (long long)ldw, Y, (long long)N, Z, nblk);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL((k3_wtz_kernel<P>), dim3((unsigned)nseg, (unsigned)(Np / 128)), dim3(256), 0, h->stream, W, (long long)ldw,
+                     (long long)Np, (const double*)Z, part, nseg);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL((k3_reduce_kernel<P>), dim3((unsigned)((N * P + 255) / 256)), dim3(256), 0, h->stream, (const double*)part,
+                     (long long)Np, (long long)N, nseg, alpha);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
 inline int half_split(int64_t n) { return (int)(((n / NB) / 2) * NB); }
 
 template <typename T> constexpr int dt();
@@ -733,6 +869,18 @@ extern "C" int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t 
   GPK_REQUIRE(h, Np % NB == 0 && N >= 1 && N <= Np && ldw >= Np, "potrs_inv: bad sizes");
   GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P, "potrs_inv: P must be in [1, 16]");
   const int nb = h->batch;
+  // large models with a handful of targets: two streaming passes over W (HBM-bound) instead of two tile GEMMs on a
+  // 128-column panel; small models keep the two GEMM launches (latency-bound there)
+  if (nb == 1 && P <= 6 && Np >= h->k3_stream_min_np && ldw % 2 == 0 && ((uintptr_t)W % 16) == 0) {
+    switch (P) {
+      case 1: return k3_stream<1>(h, W, Np, ldw, Y, N, alpha);
+      case 2: return k3_stream<2>(h, W, Np, ldw, Y, N, alpha);
+      case 3: return k3_stream<3>(h, W, Np, ldw, Y, N, alpha);
+      case 4: return k3_stream<4>(h, W, Np, ldw, Y, N, alpha);
+      case 5: return k3_stream<5>(h, W, Np, ldw, Y, N, alpha);
+      default: return k3_stream<6>(h, W, Np, ldw, Y, N, alpha);
+    }
+  }
   const long long panel = Np * NB;                         // doubles per problem and panel
   void* ws = nullptr;
   GPK_TRY(gpk_scratch(h, (size_t)2 * nb * panel * sizeof(double), &ws));

@@ -38,6 +38,7 @@ struct gpk_context {
   int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
+  int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
   int k5_split_form = 1;     // bf16 x 3 variance launch: 1 = 32x32x16 MFMAs, register-staged; 2 = 16x16x32 fused-term MFMAs,
                              // LDS filled by DMA (GPK_K5_SPLIT_FORM)
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request

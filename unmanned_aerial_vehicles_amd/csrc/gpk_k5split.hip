@@ -19,6 +19,8 @@
 // per-column sums of squares (fp64) instead of storing it.
 //
 // Replaces the same reference lines as gpk_predict_var_inv (sklearn/gaussian_process/_gpr.py:454-485).
+#include <cmath>
+
 #include "gpk_internal.h"
 
 namespace {
@@ -29,7 +31,10 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 template <int V> struct IntC { static constexpr int value = V; };
 
 constexpr int ROWB = 384;      // bytes of one k-tile (16 k) of a quad of rows: 4 rows x 2 halves x 3 parts x 16 B
-constexpr int LROW = 112;      // padded LDS row
+// the same two constants for NPART parts per value (3: bf16 x 3, exact; 2: fp16 x 2, 22 significant bits)
+template <int NPART> constexpr int rowb_v = 4 * 2 * NPART * 16;
+template <int NPART> constexpr int lrow_v = 2 * NPART * 16 + 16;      // 112 / 80 bytes = 4 x odd dwords: conflict-free b128 reads
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // bf16 part of a finite fp32 value, rounded to nearest even (as bits in the upper half of a dword)
 __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
@@ -74,6 +79,33 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
   d[0] = f[0]; d[1] = f[1]; d[2] = f[2];
 }
 
+// ---- fp16 x 2 split (the optional fast form): x * scale = h0 + h1 + r with h0, h1 fp16 (rounded to nearest), |r| <= 2^-22 |x|
+// for values whose second part is a normal fp16 number (|x * scale| >= 2^-3) and <= 2^-25 * 2^15 / scale absolutely
+// below that; `scale` (a power of two chosen by the caller so that max |x * scale| <= 2^15) puts the operand's
+// largest entries at the top of fp16's range.  Chunk order [row / 4][k16 block][row % 4][half][part]: 64 bytes per row
+// and k-tile, 256 contiguous bytes per quad of rows.
+__global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ src, long long rows, long long cols,
+                                                     long long ld, float scale, V16* __restrict__ dst) {
+  const long long hc = cols / 8;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * hc) return;
+  const long long row = e / hc, hb = e - row * hc;
+  const float4* s4 = reinterpret_cast<const float4*>(src + row * ld + hb * 8);
+  const float4 lo = s4[0], hi = s4[1];
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  f16x8 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * scale;
+    const _Float16 h0 = (_Float16)x;
+    p0[j] = h0;
+    p1[j] = (_Float16)(x - (float)h0);
+  }
+  V16* d = dst + (((row >> 2) * (hc >> 1) + (hb >> 1)) * 4 + (row & 3)) * 4 + (hb & 1) * 2;
+  d[0] = __builtin_bit_cast(V16, p0);
+  d[1] = __builtin_bit_cast(V16, p1);
+}
+
 struct SParams {
   const char* A;        // W, split layout, Np rows
   const char* B;        // Kq, split layout, Mp rows
@@ -93,13 +125,15 @@ __device__ __forceinline__ void load3(const char* __restrict__ ubase, const unsi
 
 // WR wave rows x 2 wave columns of 64 x 64 per workgroup: WR = 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU;
 // WR = 4 -> 256 x 128 tile, 8 waves, 1 workgroup per CU (25 % less operand staging per MFMA)
-template <int WR>
+// NPART = 3: bf16 parts, six products per block (exact); NPART = 2: fp16 parts, three products (a1 b0, a0 b1, a0 b0)
+template <int WR, int NPART = 3>
 __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
+  constexpr int LROW = lrow_v<NPART>, ROWB = rowb_v<NPART>, CPR = 2 * NPART;      // (shadow the bf16 x 3 constants)
   constexpr int TMR = 64 * WR;                                     // tile rows
   constexpr int SSZ = (TMR + 128) * LROW;                          // one LDS stage: [A k-tile | B k-tile]
   constexpr int BOFF = TMR * LROW;                                 // B inside a stage
   __shared__ __attribute__((aligned(16))) char lds[2 * SSZ];
-  constexpr int NT = WR * 128, AB = 2, NCH = (TMR + 128) * 6, NQ = (NCH + NT - 1) / NT;   // threads, blocks, chunks
+  constexpr int NT = WR * 128, AB = 2, NCH = (TMR + 128) * CPR, NQ = (NCH + NT - 1) / NT;   // threads, blocks, chunks
   constexpr int GSZ = WR == 2 ? 64 : 32;                           // resident workgroups per XCD = tiles per group
   constexpr int BH = 1024 / TMR;                                   // band height in tile rows (1024 matrix rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,9 +184,9 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   for (int q = 0; q < NQ; ++q) {
     const int g = tid + NT * q;
     live[q] = __builtin_amdgcn_readfirstlane(g < NCH ? 1 : 0) != 0;
-    isb[q] = __builtin_amdgcn_readfirstlane(g >= TMR * 6 ? 1 : 0) != 0;
-    const int c = live[q] ? (isb[q] ? g - TMR * 6 : g) : 0, row = c / 6, w = c - row * 6;
-    goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * 6 + w) * 16);     // rsa: bytes between row quads
+    isb[q] = __builtin_amdgcn_readfirstlane(g >= TMR * CPR ? 1 : 0) != 0;
+    const int c = live[q] ? (isb[q] ? g - TMR * CPR : g) : 0, row = c / CPR, w = c - row * CPR;
+    goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * CPR + w) * 16);     // rsa: bytes between row quads
     lofs[q] = (isb[q] ? BOFF : 0) + row * LROW + w * 16;
   }
   const char* ua = p.A + (long long)(row0 >> 2) * p.rsa;
@@ -188,33 +222,41 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
 #define GPK_K5S_FPRE 1
 #endif
   const int fr = lane & 31, fh = lane >> 5;
-  auto mfmas = [&](const bf16x8 (&af)[AB][3], const bf16x8 (&bf)[2][3]) {
+  auto mfmas = [&](const bf16x8 (&af)[AB][NPART], const bf16x8 (&bf)[2][NPART]) {
     // smallest terms first
 #pragma unroll
     for (int a = 0; a < AB; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         f16v c = acc[a][b];
+        if constexpr (NPART == 2) {
+          const f16x8 a0 = __builtin_bit_cast(f16x8, af[a][0]), a1 = __builtin_bit_cast(f16x8, af[a][1]);
+          const f16x8 b0 = __builtin_bit_cast(f16x8, bf[b][0]), b1 = __builtin_bit_cast(f16x8, bf[b][1]);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+        } else {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
+        }
         acc[a][b] = c;
       }
   };
-  auto frags = [&](const char* buf, bf16x8 (&af)[AB][3], bf16x8 (&bf)[2][3]) {
+  auto frags = [&](const char* buf, bf16x8 (&af)[AB][NPART], bf16x8 (&bf)[2][NPART]) {
 #pragma unroll
     for (int a = 0; a < AB; ++a)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + (row_w + 32 * a + fr) * LROW + (fh * 3 + s) * 16));
+      for (int s = 0; s < NPART; ++s)
+        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + (row_w + 32 * a + fr) * LROW + (fh * NPART + s) * 16));
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + BOFF + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
+      for (int s = 0; s < NPART; ++s)
+        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + BOFF + (col_w + 32 * b + fr) * LROW + (fh * NPART + s) * 16));
   };
 #if GPK_K5S_FPRE
   // Fragments one k-tile ahead: while the MFMAs of k-tile kt run out of registers F[kt & 1], the fragments of k-tile
@@ -222,7 +264,7 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   // (its previous content, k-tile kt, was read during iteration kt-1; the barrier at the end of each iteration
   // separates the two).  No MFMA waits for LDS.
   static_assert(RING == 2, "the fragment-prefetch pipeline is written for a ring of two k-tiles");
-  bf16x8 FA[2][AB][3], FB[2][2][3];
+  bf16x8 FA[2][AB][NPART], FB[2][2][NPART];
   fetch(0, IntC<0>{});
   stage(lds, IntC<0>{});
   fetch(1, IntC<1>{});
@@ -239,11 +281,12 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
     frags(lds + (cur ^ 1) * SSZ, FA[cur ^ 1], FB[cur ^ 1]);
     mfmas(FA[cur], FB[cur]);
 #if GPK_K5S_SCHED
+    constexpr int NMF = (NPART == 3 ? 6 : 3) * AB * 2, NRD = NPART * (AB + 2);
     __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
 #pragma unroll
     for (int g = 0; g < NQ; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 12 * AB / NQ, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, (3 * AB + 6) / NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, (NMF + NQ - 1) / NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NQ - 1) / NQ, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 #endif
@@ -263,17 +306,17 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
     constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
     stage(lds + (cur ^ 1) * SSZ, IntC<sl>{});
     fetch(kt + 1 + RING, IntC<sl>{});
-    bf16x8 af[AB][3], bf[2][3];
+    bf16x8 af[AB][NPART], bf[2][NPART];
     frags(lds + cur * SSZ, af, bf);
     mfmas(af, bf);
 #if GPK_K5S_SCHED
     // issue order: LDS writes of the next k-tile, all twelve fragment reads, then the MFMAs with the six
     // buffer loads spread among them (the scheduler otherwise trickles the reads between MFMAs and waits five times)
     __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 3 * AB + 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NPART * (AB + 2), 0);
 #pragma unroll
     for (int g = 0; g < NQ; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 12 * AB / NQ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, ((NPART == 3 ? 6 : 3) * AB * 2 + NQ - 1) / NQ, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 #endif
@@ -330,7 +373,7 @@ constexpr int V2_TM = 256, V2_TN = 128;
 constexpr int V2_STAGE = (V2_TM + V2_TN) * 96;      // 36864 bytes: [A k-tile | B k-tile]
 constexpr int V2_BOFF = V2_TM * 96;
 constexpr int V2_NSTG = 4;
-constexpr int V2_NDMA = V2_STAGE / 1024;            // 36 wave instructions per stage: 24 of A, 12 of B
+// (36 wave instructions of 1 KiB per stage: 24 of A, 12 of B)
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -519,6 +562,55 @@ extern "C" int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t 
                      (long long)cols, (long long)ld, (V16*)dst);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
+}
+
+extern "C" int gpk_split2(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, double scale, void* dst) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, src && dst, "split2: null pointer");
+  GPK_REQUIRE(h, rows >= 4 && rows % 4 == 0 && cols >= 16 && cols % 16 == 0 && ld >= cols && ld % 4 == 0,
+              "split2: rows must be a multiple of 4 and cols a multiple of 16");
+  GPK_REQUIRE(h, ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split2: buffers must be 16-byte aligned");
+  int ex = 0;
+  GPK_REQUIRE(h, scale > 0.0 && std::frexp(scale, &ex) == 0.5, "split2: scale must be a power of two");
+  const long long n = rows * (cols / 8);
+  hipLaunchKernelGGL(split2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, (long long)rows,
+                     (long long)cols, (long long)ld, (float)scale, (V16*)dst);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+                                          const void* W2, double w_scale, int64_t Np, const float* Xq, int64_t M,
+                                          double kss, double floor_, float* work, void* work2, double* var) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && W2 && Xq && work && work2 && var, "predict_var_inv_split2: null pointer");
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && Np == gpk_padded(N), "predict_var_inv_split2: Np must equal gpk_padded(N)");
+  GPK_REQUIRE(h, h->batch == 1, "predict_var_inv_split2: not available in batched mode");
+  GPK_REQUIRE(h, w_scale > 0.0 && sf2 > 0.0, "predict_var_inv_split2: scales must be positive");
+  const int64_t Mp = gpk_padded(M);
+  const int ntm = (int)(Np / 128), ntn = (int)(Mp / 128);
+  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 4 * 128 < (1ll << 31), "predict_var_inv_split2: size too large");
+  // K* in (0, sf2]: the power of two that puts sf2 just below 2^15
+  const double k_scale = std::ldexp(1.0, 14 - (int)std::floor(std::log2(sf2)));
+  GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
+  GPK_TRY(gpk_split2(h, work, Mp, Np, Np, k_scale, work2));
+  const int wr = (Np % 256 == 0) ? 4 : 2;
+  const int ntmT = (int)(Np / (64 * wr)), gsz = wr == 2 ? 64 : 32;
+  void* partial = nullptr;
+  GPK_TRY(gpk_scratch(h, (size_t)ntmT * Mp * sizeof(double), &partial));
+  SParams p;
+  p.A = (const char*)W2; p.B = (const char*)work2; p.out = (double*)partial;
+  p.rsa = Np * 16; p.rsb = Np * 16; p.Mp = Mp;      // bytes between consecutive quads of rows (4 rows x 4 bytes per entry)
+  p.ntm = ntm; p.ntn = ntn;
+  p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
+  p.alpha = (float)(1.0 / (w_scale * k_scale));      // undo both operand scalings (powers of two: exact)
+  const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
+  gpk_time_begin(h, GPK_TIMED_K5);
+  if (wr == 4) hipLaunchKernelGGL((k5_split_kernel<4, 2>), dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  else hipLaunchKernelGGL((k5_split_kernel<2, 2>), dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
+  gpk_time_end(h);
+  GPK_LAUNCH_CHECK(h);
+  return gpk_colsum_finalize(h, (const double*)partial, ntmT, Mp, M, kss, floor_, var);
 }
 
 extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,

@@ -454,6 +454,29 @@ class DeviceGP:
                 self._Winv.pop("f32", None)      # the plain fp32 copy only served as the source of the split
         return self._Winv["split"]
 
+    def split2_inverse_factor(self):
+        """The fp32 inverse factor as two fp16 parts per entry (gpk_split2 layout, 4 bytes per entry) and the power
+        of two it was scaled by: the operand of the optional fast variance launch (`method="inverse_split2"`)."""
+        torch = _torch()
+        if "split2" not in self._Winv:
+            had_f32 = "f32" in self._Winv
+            Wf = self.inverse_factor(True)
+            # largest |W_ij| over the lower triangle (what lies right of the zero band is not part of W), block by block
+            wmax = 0.0
+            for r0 in range(0, self.Np, 4096):
+                r1 = min(self.Np, r0 + 4096)
+                wmax = max(wmax, float(torch.tril(Wf[r0:r1, :r1], diagonal=r0).abs().max()))
+            scale = 2.0 ** int(np.floor(np.log2(32768.0 / max(wmax, 1e-300))))
+            be = self.be
+            W2 = be.empty((self.Np * self.Np * 4,), torch.uint8)
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_split2(be.h, _p(Wf), self.Np, self.Np, self.Np, float(scale), _p(W2)))
+            self._Winv["split2"] = (W2, float(scale))
+            if not had_f32:
+                self._Winv.pop("f32", None)
+        return self._Winv["split2"]
+
     # ---- fp32 serving gates -------------------------------------------------------------------------------------
     # The fp32 predict path is stated as: mean within 1e-4, std within 1e-3 (relative to the largest value) of the
     # fp64 path.  An fp32 kernel value carries the rounding of its exponent - an ulp of d^2/2 ~ 10 is 1e-6 - so every
@@ -499,16 +522,18 @@ class DeviceGP:
         explicit inverse factor W = L^-1, formed once per factorisation, in ONE fused GEMM launch (fp64 MFMA, or
         the exact-fp32 MFMA); "inverse_split" (fp32 only): the same launch on the bf16 matrix pipe with both fp32
         operands split exactly into three bf16 parts (fp32 accuracy, 1.5x the fp32 MFMA's speed); "auto":
-        "inverse" for fp64, "inverse_split" for fp32."""
+        "inverse" for fp64, "inverse_split" for fp32.  "inverse_split2" (fp32 only, never chosen automatically): the
+        same launch with an fp16 x 2 operand split and three products per block - 22 instead of 24 significant bits per
+        product, half the matrix-pipe work."""
         torch = _torch()
         assert self.factored
         f32 = dtype in ("float32", np.float32, torch.float32)
         if method == "auto":
             method = "inverse_split" if f32 else "inverse"
-        if method not in ("solve", "inverse", "inverse_split"):
-            raise ValueError("method must be 'auto', 'solve', 'inverse' or 'inverse_split'")
-        if method == "inverse_split" and not f32:
-            raise ValueError("inverse_split is the fp32 serving form (exact bf16x3 operand split)")
+        if method not in ("solve", "inverse", "inverse_split", "inverse_split2"):
+            raise ValueError("method must be 'auto', 'solve', 'inverse', 'inverse_split' or 'inverse_split2'")
+        if method in ("inverse_split", "inverse_split2") and not f32:
+            raise ValueError("inverse_split / inverse_split2 are fp32 serving forms (bf16x3 / fp16x2 operand splits)")
         tdt = torch.float32 if f32 else torch.float64
         es = 4 if f32 else 8
         code = GPK_F32 if f32 else GPK_F64
@@ -520,6 +545,8 @@ class DeviceGP:
         Xd = self._f32_data()["X"] if f32 else self.X
         if method == "inverse_split":
             W3 = self.split_inverse_factor()
+        elif method == "inverse_split2":
+            W2, w_scale = self.split2_inverse_factor()
         elif method == "inverse":
             Wd = self.inverse_factor(f32)
         elif f32:
@@ -530,7 +557,8 @@ class DeviceGP:
         panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * es)) // 128 * 128))
         panel = min(panel, padded(M))
         work = self.be.empty((self.Np * panel,), tdt)
-        work3 = self.be.empty((self.Np * panel * 6,), torch.uint8) if method == "inverse_split" else None
+        work3 = (self.be.empty((self.Np * panel * (6 if method == "inverse_split" else 4),), torch.uint8)
+                 if method in ("inverse_split", "inverse_split2") else None)
         var = self.be.empty((panel,), torch.float64)
         be = self.be
         lsp = self.ls.ctypes.data_as(_lib._dp)
@@ -542,6 +570,10 @@ class DeviceGP:
                     be.check(be.lib.gpk_predict_var_inv_split(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W3),
                                                               self.Np, _p(q[m0:m1]), m1 - m0, float(kss), float(floor),
                                                               _p(work), _p(work3), _p(var)))
+                elif method == "inverse_split2":
+                    be.check(be.lib.gpk_predict_var_inv_split2(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W2),
+                                                               w_scale, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
+                                                               float(floor), _p(work), _p(work3), _p(var)))
                 elif method == "inverse":
                     be.check(be.lib.gpk_predict_var_inv(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Wd),
                                                         self.Np, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),

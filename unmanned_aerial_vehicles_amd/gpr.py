@@ -53,7 +53,7 @@ class GaussianProcessRegressor:
         self.random_state = random_state
         self.device = device
         self.predict_dtype = predict_dtype
-        self.var_method = var_method      # 'auto' | 'inverse' | 'solve' | 'inverse_split' (fp32 only): DeviceGP.predict_var_dev
+        self.var_method = var_method      # 'auto' | 'inverse' | 'solve' | 'inverse_split' | 'inverse_split2' (fp32 only): DeviceGP.predict_var_dev
         self.fp32_gate = True             # predict_dtype="float32": route ill-conditioned models / tiny variances to fp64
         self._dev = None
 
@@ -238,7 +238,7 @@ class GaussianProcessRegressor:
         vm = self.var_method
         if gated and not dev.fp32_mean_ok():
             pd = "float64"
-            vm = "auto" if vm == "inverse_split" else vm      # (the split launch is an fp32 form)
+            vm = "auto" if vm in ("inverse_split", "inverse_split2") else vm      # (the split launches are fp32 forms)
         q = dev.be.upload(X, torch.float32 if pd == "float32" else torch.float64)
         mean_d = dev.predict_mean_dev(q, self._y_train_mean, self._y_train_std, pd).double()
         if not return_std:
