@@ -56,14 +56,16 @@ def parse_args(argv=None):
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra timing of the other variance paths")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "gram"],
                     help="c3 (default, the headline): mean+var for 10 000 queries per GPU per step, weak scaling; "
                          "c4: BASELINE configs[3] - 1 048 576 queries in total sharded over the GPUs, posterior means "
-                         "only, RCCL all-gather of the means (strong scaling)")
-    ap.add_argument("--var-method", default="auto", choices=["auto", "inverse_split", "inverse", "solve"],
+                         "only, RCCL all-gather of the means (strong scaling); gram: the fp64 RBF Gram build at N_train, "
+                         "row-sharded over the GPUs with no exchange (SURVEY 8e; strong scaling, GB/s)")
+    ap.add_argument("--var-method", default="auto", choices=["auto", "inverse_split", "inverse_split2", "inverse", "solve"],
                     help="auto = inverse_split: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch on the "
                          "bf16 matrix pipe with both fp32 operands split exactly into three bf16 parts (fp32 accuracy); "
-                         "inverse: the same launch on the exact-fp32 MFMA; solve: blocked triangular solve chain")
+                         "inverse: the same launch on the exact-fp32 MFMA; solve: blocked triangular solve chain; inverse_split2: "
+                         "the optional fp16 x 2 split (three products per block, 22-bit products) - not the headline")
     return ap.parse_args(argv)
 
 
@@ -192,6 +194,71 @@ def pmc_traffic(kernel_key, N, M):
     return None
 
 
+def bench_gram(args, be, rank, world, use_dist, ranks_seen):
+    """--workload gram: K1 alone, sharded by row slabs (each rank writes the rows it owns; nothing is exchanged)."""
+    import torch
+    import torch.distributed as dist
+    from unmanned_aerial_vehicles_amd import _lib
+    from unmanned_aerial_vehicles_amd.sharded import gram_slab_bounds, sharded_gram
+    N, D = args.n_train, 9
+    X, _, _ = synthetic_problem(N, 1)
+    Xd = be.upload(X)
+    row0, nrows = gram_slab_bounds(N, world, rank)
+    Np = (N + 127) // 128 * 128
+    slab = be.empty((nrows, Np), torch.float64)
+
+    def sync_all():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        sharded_gram(Xd, 2.0, 1.0, 0.1001, world, rank, be, out=slab)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sync_all()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step()
+        b.record()
+        evs.append((a, b))
+    sync_all()
+    dt = time.perf_counter() - t0
+    mine = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=be.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = bool(torch.isfinite(slab).all()) and (nrows == 0 or float(slab[0, row0]) == 1.0 + 0.1001)
+    assert ok, "Gram slab check failed"
+    if rank == 0:
+        total_bytes = float(Np) * Np * 8 + float(N) * D * 8          # SURVEY 8d: N^2 s + N D s
+        my_bytes = float(nrows) * Np * 8 + float(N) * D * 8
+        line = {"metric": "RBF Gram build GB/s (fp64, row-sharded over the GPUs) at N_train=65536, D=9",
+                "value": total_bytes * args.steps / dt / 1e9, "unit": "GB/s", "n_gpus": world, "ranks_seen": ranks_seen,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"K1: N_train={N}, D={D}, fp64 Gram matrix ({Np} x {Np}), rows dealt to {world} GPU(s) "
+                                       f"in 128-row tiles, no exchange", "n_train": N, "features": D,
+                           "rows_of_rank0": nrows,
+                           "kernel": "gram_strip_kernel (symmetric tiles computed once, written twice)" if world == 1
+                                     else "cross_t_kernel per slab (every entry computed directly: no mirroring across ranks)"},
+                "roofline": {"bound": "hbm" if world == 1 else "valu", "achieved": my_bytes / mine / 1e9, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": my_bytes / mine / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                             "kernel_ms": mine * 1e3,
+                             "note": "rank 0's slab bytes over its own launch time (HIP events); a slab kernel computes every "
+                                     "entry (about 45 fp64 operations each), so from two ranks up it is bound by the "
+                                     "fp64 vector rate rather than by HBM"}}
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     # (BENCH_FORCE_LAUNCH=1 takes the same parent -> torch.distributed.run -> rank route with one rank: the way to
@@ -240,6 +307,8 @@ def main():
     from unmanned_aerial_vehicles_amd.sharded import all_gather_rows
 
     be = get_backend(local_rank)
+    if args.workload == "gram":
+        return bench_gram(args, be, rank, world, use_dist, ranks_seen)
     c4 = args.workload == "c4"
     if c4:
         args.queries = (1 << 20) // world          # strong scaling: the 1 M queries are split over the ranks
@@ -275,7 +344,7 @@ def main():
     torch.cuda.synchronize()
     potrf_s = time.perf_counter() - t0
     dev.factored = True
-    use_w = not c4 and method in ("inverse", "inverse_split")
+    use_w = not c4 and method in ("inverse", "inverse_split", "inverse_split2")
     if use_w:
         # the inverse factor (34 GB) and its scratch come from torch's caching allocator: map them once outside the
         # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
@@ -290,6 +359,8 @@ def main():
         trtri_s = time.perf_counter() - t0
         if method == "inverse_split":
             dev.split_inverse_factor()             # ... served as three exact bf16 parts per entry (6 bytes)
+        elif method == "inverse_split2":
+            dev.split2_inverse_factor()            # ... served as two fp16 parts per entry (4 bytes)
         else:
             dev.inverse_factor(True)               # ... served as an fp32 copy
     elif not c4:
@@ -310,6 +381,7 @@ def main():
            "alpha_solve_ms": alpha_s * 1e3,
            "variance_prep": "none (means only)" if c4 else
                             {"inverse_split": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + exact bf16x3 split",
+                             "inverse_split2": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp16x2 split",
                              "inverse": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy",
                              "solve": "fp32 copy of L"}[method],
            "variance_prep_s": prep_s, "trtri_s": trtri_s,
@@ -414,6 +486,11 @@ def main():
             executed = 6.0 * flops
             kernel = ("k5_split_kernel<4> (V = W K*^T, fp32 operands as 3 exact bf16 parts, 6 x v_mfma_f32_32x32x16_bf16 per "
                       "32x32x16 block product, fp32 accumulation, fused column-norm epilogue, 1 launch/step)")
+        elif method == "inverse_split2":
+            key, peak = "k5_split2_kernel", MFMA_BF16_PEAK_TF        # fp16 MFMA: the same rate as bf16
+            executed = 3.0 * flops
+            kernel = ("k5_split_kernel<4,2> (V = W K*^T, fp32 operands as 2 fp16 parts, 3 x v_mfma_f32_32x32x16_f16 per "
+                      "32x32x16 block product, fp32 accumulation, fused column-norm epilogue, 1 launch/step)")
         else:
             key, peak = ("gemm_kernel_f32_epi1", MFMA_F32_PEAK_TF)
             executed = flops
@@ -424,10 +501,11 @@ def main():
         roof = {"bound": "mfma", "kernel": kernel,
                 "achieved": executed / k5_s / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": executed / k5_s / 1e12 / peak,
-                "pipe": "bf16 MFMA" if method == "inverse_split" else "fp32 MFMA",
+                "pipe": {"inverse_split": "bf16 MFMA", "inverse_split2": "fp16 MFMA"}.get(method, "fp32 MFMA"),
                 "algorithmic_flops_per_launch": executed,
                 "algorithmic_flops_note": "N^2 M fp32-equivalent flops (SURVEY 8d)" +
-                                          (" x 6 bf16 MFMA products per fp32-equivalent product" if method == "inverse_split" else ""),
+                                          {"inverse_split": " x 6 bf16 MFMA products per fp32-equivalent product",
+                                           "inverse_split2": " x 3 fp16 MFMA products per fp32-equivalent product"}.get(method, ""),
                 "fp32_equivalent_TFLOPs": flops / k5_s / 1e12,
                 "traffic": tr["bytes_per_launch"] if tr else None,
                 "traffic_source": tr["source"] if tr else None,
@@ -527,7 +605,9 @@ def main():
                        "arithmetic": "fp32 operands and accumulation" +
                                      ("; products on the bf16 MFMA pipe from an exact 3-way bf16 split of every fp32 "
                                       "operand (error class of the fp32 MFMA, checked under \"parity\")"
-                                      if (method == "inverse_split" and not c4) else ""),
+                                      if (method == "inverse_split" and not c4) else
+                                      ("; products on the fp16 MFMA pipe from a 2-way fp16 split (22 significant bits per "
+                                       "operand): the optional fast form" if (method == "inverse_split2" and not c4) else "")),
                        "parallelism": f"query-sharded x{world}, model replicated (every rank fits redundantly)" +
                                       ((", RCCL all-gather of the means" if c4 else ", RCCL all-gather of [mean|var]")
                                        if use_dist else "")},

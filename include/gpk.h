@@ -97,6 +97,14 @@ const char* gpk_version(void);
 int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
              double sf2, double diag_add, void* K, int64_t ldk);
 
+/* Row slab of the same matrix, for a Gram build sharded over GPUs by rows (no exchange: rank r writes the rows it
+ * owns; the slabs only have to meet on one device if that device is to factorise): Kslab (dev, gpk_padded(nrows) x ldk)
+ * receives rows row0 .. row0 + gpk_padded(nrows) - 1 of the padded matrix gpk_gram would write - every entry computed
+ * directly (no symmetric mirroring across slabs), diagonal = sf2 + diag_add, identity in the padding.  row0 % 128 == 0.
+ * Replaces the same reference lines as gpk_gram.                                                                    */
+int gpk_gram_rows(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls, double sf2,
+                  double diag_add, int64_t row0, int64_t nrows, void* Kslab, int64_t ldk);
+
 /* Cross kernel, transposed layout: B[j][m] = sf2 * exp(-0.5 ||(x_j - xq_m)/ls||^2) for
  * j < N, m < M; zero elsewhere in the (Np x Mp) padded block.  No white noise.
  * Replaces: sklearn/gaussian_process/kernels.py:1564-1565 (cdist + exp).

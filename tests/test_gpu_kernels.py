@@ -145,6 +145,31 @@ def test_gram_fp64(be, csv_data, N, D, ard):
     assert np.array_equal(pad, expect)                               # identity padding
 
 
+@pytest.mark.parametrize("N,world", [(1000, 1), (1000, 3), (700, 8), (130, 4)])
+def test_gram_row_slabs(be, csv_data, N, world):
+    """Row-sharded Gram build: the slabs of every rank, stacked, are the padded matrix gpk_gram writes
+    (same entries: same exact differences and exp; identity padding; diagonal sf2 + diag_add), fp64 and fp32."""
+    import torch
+    from unmanned_aerial_vehicles_amd import gram_slab_bounds, sharded_gram
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    X = csv_data["X10"][:N, :9]
+    ls = 0.4 + 0.05 * np.arange(9)
+    dev = DeviceGP(X, np.zeros((N, 1)), be)
+    dev.gram(ls, 1.3, 0.25)
+    full = dev.K.cpu().numpy()
+    rows = []
+    for r in range(world):
+        slab, row0 = sharded_gram(X, ls, 1.3, 0.25, world, r, be)
+        assert (row0, slab.shape[0]) == gram_slab_bounds(N, world, r) and slab.shape[1] == dev.Np
+        rows.append(slab.cpu().numpy())
+    stacked = np.concatenate(rows, axis=0)
+    assert stacked.shape == full.shape
+    assert np.max(np.abs(stacked - full)) <= 4 * np.finfo(np.float64).eps * 1.3      # (the fused kernel mirrors tiles; here every entry is direct)
+    assert np.array_equal(stacked[N:], full[N:]) and np.array_equal(np.diag(stacked), np.diag(full))
+    slab32, _ = sharded_gram(X, ls, 1.3, 0.25, world, 0, be, dtype="float32")
+    assert np.max(np.abs(slab32.double().cpu().numpy() - rows[0])) < 2e-6 * 1.3
+
+
 def test_gram_fp32(be, csv_data):
     import torch
     from unmanned_aerial_vehicles_amd import _lib

@@ -261,6 +261,19 @@ def test_shard_bounds():
                 assert cover[0][0] == 0 and cover[-1][1] == M and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
+def test_gram_slab_bounds():
+    from unmanned_aerial_vehicles_amd import gram_slab_bounds
+    for N in (1, 127, 128, 129, 1000, 65536, 65537):
+        ntiles = (N + 127) // 128
+        for W in (1, 2, 3, 8, 600):
+            nxt = 0
+            for r in range(W):
+                row0, nrows = gram_slab_bounds(N, W, r)
+                assert row0 % 128 == 0 and nrows % 128 == 0 and (nrows == 0 or row0 == nxt)
+                nxt = row0 + nrows if nrows else nxt
+            assert nxt == 128 * ntiles                      # the slabs tile the padded matrix exactly
+
+
 def test_bench_self_launch_without_touching_the_gpu(tmp_path):
     """`python bench.py --gpus N` (N > 1, no RANK in the environment) starts the ranks as a child
     torch.distributed.run job before torch is imported, relays rank 0's JSON line and exits with the child's

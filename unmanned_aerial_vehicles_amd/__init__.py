@@ -7,7 +7,7 @@ kernels).  Public surface mirrors the reference's seams:
     SimpleQuadrotorGP, SimpleGPEnhancedMPC                        (model seam, simple_gp.py)
     GaussianProcess                                               (ROS-package GP, package_gp.py)
     GPTrainer, PreTrainedGP                                       (per-output ARD GPs, trainer.py)
-    evaluate_gp, ShardedPredictor
+    evaluate_gp, ShardedPredictor, sharded_gram
 """
 from .kernels import RBF, ConstantKernel, WhiteKernel  # noqa: F401
 from .gpr import GaussianProcessRegressor  # noqa: F401
@@ -16,8 +16,8 @@ from .package_gp import GaussianProcess  # noqa: F401
 from .trainer import GPTrainer, PreTrainedGP  # noqa: F401
 from .batched import BatchedARDGP  # noqa: F401
 from .evaluate import evaluate_gp  # noqa: F401
-from .sharded import ShardedPredictor, shard_bounds, sharded_predict  # noqa: F401
+from .sharded import ShardedPredictor, gram_slab_bounds, shard_bounds, sharded_gram, sharded_predict  # noqa: F401
 
 __all__ = ["GaussianProcessRegressor", "RBF", "WhiteKernel", "ConstantKernel", "SimpleQuadrotorGP",
            "SimpleGPEnhancedMPC", "GaussianProcess", "GPTrainer", "PreTrainedGP", "evaluate_gp",
-           "ShardedPredictor", "shard_bounds", "sharded_predict", "BatchedARDGP"]
+           "ShardedPredictor", "shard_bounds", "sharded_predict", "sharded_gram", "gram_slab_bounds", "BatchedARDGP"]

@@ -46,6 +46,7 @@ SIGNATURES = {
     "gpk_batch_end": (_int, [_vp]),
     "gpk_version": (C.c_char_p, []),
     "gpk_gram": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _i64]),
+    "gpk_gram_rows": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _dbl, _i64, _i64, _vp, _i64]),
     "gpk_cross_gram_t": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _int, _dp, _dbl, _vp, _i64]),
     "gpk_potrf": (_int, [_vp, _vp, _i64, _i64, _vp, C.POINTER(_int)]),
     "gpk_leaf_inverses": (_int, [_vp, _vp, _i64, _i64, _vp]),

@@ -654,6 +654,48 @@ extern "C" int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t 
   return GPK_OK;
 }
 
+// ---- row slab of the padded Gram matrix (multi-GPU build: every rank writes the rows it owns, no exchange) --------
+// diagonal of the slab's rows: sf2 + diag_add inside the data, 1 in the identity padding
+template <typename T>
+__global__ void slab_diag_kernel(T* __restrict__ K, long long ldk, long long row0, long long nrows_p, long long N,
+                                 long long Np, T dval) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows_p) return;
+  const long long i = row0 + r;
+  if (i < Np) K[r * ldk + i] = i < N ? dval : T(1);
+}
+
+extern "C" int gpk_gram_rows(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls, double sf2,
+                             double diag_add, int64_t row0, int64_t nrows, void* Kslab, int64_t ldk) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && Kslab && N >= 1, "gram_rows: null pointer or empty input");
+  const int64_t Np = gpk_padded(N), nrp = gpk_padded(nrows);
+  GPK_REQUIRE(h, row0 >= 0 && row0 % GPK_TILE == 0 && nrows >= 1 && row0 + nrp <= Np,
+              "gram_rows: row0 must be a multiple of 128 and the slab must lie inside the padded matrix");
+  GPK_REQUIRE(h, ldk >= Np && ldk % 4 == 0, "gram_rows: ldk must be >= gpk_padded(N)");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "gram_rows: bad dtype");
+  const size_t es = dtype == GPK_F64 ? 8 : 4;
+  const int64_t valid = row0 >= N ? 0 : (N - row0 < nrp ? N - row0 : nrp);      // data rows of the slab
+  if (valid > 0) {
+    // rows = this slab's training points, columns = all training points: the cross-kernel block (zero in the padding)
+    GPK_TRY(gpk_cross_gram_t(h, dtype, (const char*)X + (size_t)row0 * D * es, valid, X, N, D, ls, sf2, Kslab, ldk));
+    if (gpk_padded(valid) < nrp)
+      GPK_CHECK_HIP(h, hipMemsetAsync((char*)Kslab + (size_t)gpk_padded(valid) * ldk * es, 0,
+                                      (size_t)(nrp - gpk_padded(valid)) * ldk * es, h->stream));
+  } else {
+    GPK_CHECK_HIP(h, hipMemsetAsync(Kslab, 0, (size_t)nrp * ldk * es, h->stream));
+  }
+  const unsigned nb = (unsigned)((nrp + 255) / 256);
+  if (dtype == GPK_F64)
+    hipLaunchKernelGGL(slab_diag_kernel<double>, dim3(nb), dim3(256), 0, h->stream, (double*)Kslab, (long long)ldk,
+                       (long long)row0, (long long)nrp, (long long)N, (long long)Np, sf2 + diag_add);
+  else
+    hipLaunchKernelGGL(slab_diag_kernel<float>, dim3(nb), dim3(256), 0, h->stream, (float*)Kslab, (long long)ldk,
+                       (long long)row0, (long long)nrp, (long long)N, (long long)Np, (float)sf2 + (float)diag_add);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
 extern "C" int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D, int P,
                                 const double* ls, double sf2, const double* y_mean, const double* y_std,
                                 const void* Xq, int64_t M, void* mean) {

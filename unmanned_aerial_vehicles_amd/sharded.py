@@ -51,6 +51,55 @@ def sharded_predict(predict_local, Xq, group=None):
     return all_gather_rows(local, M, group)
 
 
+def gram_slab_bounds(N, world_size, rank):
+    """Rows [row0, row0 + nrows) of the padded (Np x Np) Gram matrix owned by `rank`: whole 128-row tiles, dealt in
+    contiguous runs of ceil(tiles / world_size)."""
+    ntiles = (int(N) + 127) // 128
+    per = -(-ntiles // int(world_size))
+    t0 = min(ntiles, rank * per)
+    t1 = min(ntiles, t0 + per)
+    return 128 * t0, 128 * (t1 - t0)
+
+
+def sharded_gram(X, ls, sf2, diag_add, world_size=None, rank=None, backend=None, dtype="float64", out=None):
+    """This rank's row slab of K = sf2 exp(-d^2/2) + diag_add I (the Gram build shards by row blocks
+    with no exchange).  X: (N, D) array or device tensor, identical on every rank.  Returns (slab tensor
+    (nrows, Np), row0); an empty slab (ranks beyond the tile count) has zero rows.  `out`: a tensor to reuse."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+    from .device import get_backend
+    if world_size is None:
+        on = dist.is_available() and dist.is_initialized()
+        world_size, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    be = backend or get_backend()
+    f64 = dtype in ("float64", np.float64, torch.float64)
+    tdt = torch.float64 if f64 else torch.float32
+    Xd = X.to(device=be.device, dtype=tdt).contiguous() if isinstance(X, torch.Tensor) else be.upload(np.asarray(X, dtype=np.float64), tdt)
+    N, D = Xd.shape
+    Np = (N + 127) // 128 * 128
+    row0, nrows = gram_slab_bounds(N, world_size, rank)
+    slab = out if out is not None else be.empty((nrows, Np), tdt)
+    lsv = np.ascontiguousarray(np.broadcast_to(np.asarray(ls, dtype=np.float64), (D,)))
+    if world_size == 1:
+        # one rank owns every row: the fused kernel (each symmetric tile computed once and written to both halves)
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_gram(be.h, _lib.GPK_F64 if f64 else _lib.GPK_F32, C.c_void_p(Xd.data_ptr()), N, D,
+                                     lsv.ctypes.data_as(_lib._dp), float(sf2), float(diag_add),
+                                     C.c_void_p(slab.data_ptr()), Np))
+    elif nrows:
+        with be.lock:
+            be.bind_stream()
+            be.check(be.lib.gpk_gram_rows(be.h, _lib.GPK_F64 if f64 else _lib.GPK_F32, C.c_void_p(Xd.data_ptr()), N, D,
+                                          lsv.ctypes.data_as(_lib._dp), float(sf2), float(diag_add), row0, nrows,
+                                          C.c_void_p(slab.data_ptr()), Np))
+    return slab, row0
+
+
 class ShardedPredictor:
     """Query-sharded posterior mean (+ variance) for a fitted `GaussianProcessRegressor`."""
 
