@@ -8,12 +8,13 @@
 //   A (queries, m) = [ u_q (D) | 1 | 0.. ],  B (training, n) = [ -2 u_j (D) | |u_j|^2 | 0.. ],  C_init[m][n] = |u_q|^2
 // Per pair only v_exp_f32 + P FMAs remain on the vector ALU.
 //
-//  * D <= 15 (mean_bf16_kernel): the dot product runs on the bf16 matrix pipe at fp32 accuracy.  Every fp32
+//  * D <= 14 (mean_bf16_kernel; |u_q|^2 rides along as one more component, depth D + 2): the dot product runs on the
+//    bf16 matrix pipe at fp32 accuracy.  Every fp32
 //    operand is split EXACTLY into three bf16 parts (x = x0 + x1 + x2, 8 significant bits each, by
 //    truncation; the remainders are exact in fp32) and the product becomes six v_mfma_f32_32x32x16_bf16
 //    (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0; the dropped terms are below 2^-24 of |a||b|; bf16 x bf16
 //    products are exact and accumulate in fp32): 192 matrix-pipe cycles per block.
-//  * D = 16 (mean_mfma_kernel, depth 17): nine v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  That
+//  * D = 15, 16 (mean_mfma_kernel, depth up to 17): nine v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  That
 //    instruction runs at the vector rate and was measured NOT to overlap with the exp/FMA work (it shares
 //    the fp32 lanes), which is why the bf16 split is preferred wherever the depth fits one instruction.
 //
@@ -235,12 +236,17 @@ __device__ __forceinline__ f16v chain6(const u32x4 (&a)[3], const u32x4 (&b)[3],
                a2 = __builtin_bit_cast(bf16x8, a[2]);
   const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]),
                b2 = __builtin_bit_cast(bf16x8, b[2]);
-  f16v c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, seed, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+  // Smallest terms first, the dominant product last, starting from zero (|u_q|^2 is a component of the dot product,
+  // not an accumulator seed): the five partial sums ahead of the last instruction are ~2^-8 of d, so their fp32
+  // roundings are negligible and d carries ONE rounding at its own magnitude instead of six.  The exponent's
+  // absolute error is the kernel value's relative error: this order took the mean's error constant from 3.5e-7 to
+  // 1.4e-7 per term (tools/exp_fp32_gate.py).
+  f16v c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, seed, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
   return c;
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -261,7 +267,7 @@ __device__ __forceinline__ void consume(const f16v& cur, const float (&av)[PP], 
   }
 }
 
-// D <= 15 (operand depth D + 1 <= 16).  LDS image of a staged point block (32 points): [part][half][point] x 16 B.
+// D <= 14 (operand depth D + 2 <= 16).  LDS image of a staged point block (32 points): [part][half][point] x 16 B.
 template <int PP, int QB>
 __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restrict__ X, const float* __restrict__ alpha,
                                                            long long N, int D, F16 sc, F16 ctr,
@@ -269,25 +275,21 @@ __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restri
                                                            float* __restrict__ partial) {
   __shared__ u32x4 xb[MM_TJ / 32][3][2][32];
   __shared__ float al[PP][MM_TJ];
-  __shared__ float qn_s[128 * QB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, lh = lane >> 5;
   const long long q0 = (long long)blockIdx.x * (128 * QB);
 
-  for (int t = tid; t < 128 * QB; t += 256) {
-    const long long q = q0 + t;
-    float s = 0.f;
-    if (q < M)
-      for (int d = 0; d < D; ++d) {
-        const float u = (Xq[q * D + d] - ctr.v[d]) * sc.v[d];
-        s = __builtin_fmaf(u, u, s);
-      }
-    qn_s[t] = s;
-  }
+  // A (queries) = [ u_q (D) | 1 | |u_q|^2 | 0.. ],  B (training) = [ -2 u_j (D) | |u_j|^2 | 1 | 0.. ]: depth D + 2 <= 16
   u32x4 a[QB][3];
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
     const long long q = q0 + (wave * QB + b) * 32 + ln;
+    float qn = 0.f;
+    if (q < M)
+      for (int d = 0; d < D; ++d) {
+        const float u = (Xq[q * D + d] - ctr.v[d]) * sc.v[d];
+        qn = __builtin_fmaf(u, u, qn);
+      }
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -296,16 +298,16 @@ __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restri
       if (q < M) {
         if (k < D) v[j] = (Xq[q * D + k] - ctr.v[k]) * sc.v[k];
         else if (k == D) v[j] = 1.f;
+        else if (k == D + 1) v[j] = qn;
       }
     }
     split_frag(v, a[b]);
   }
-  __syncthreads();
-  f16v seed[QB];
+  f16v seed[QB];                      // the chains start from zero
 #pragma unroll
   for (int b = 0; b < QB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) seed[b][r] = qn_s[(wave * QB + b) * 32 + acc_row(r, lane)];
+    for (int r = 0; r < 16; ++r) seed[b][r] = 0.f;
 
   f2 acc[QB][8][PP];
 #pragma unroll
@@ -333,8 +335,10 @@ __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restri
         v[d] = -2.f * u;
       }
 #pragma unroll
-      for (int d = 0; d < 16; ++d)
+      for (int d = 0; d < 16; ++d) {
         if (d == D) v[d] = tn;
+        if (d == D + 1) v[d] = in ? 1.f : 0.f;      // multiplies the queries' |u_q|^2 component
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float vh[8];
@@ -473,9 +477,9 @@ extern "C" int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* 
   S = (N + chunk - 1) / chunk;
   void* partial = nullptr;
   GPK_TRY(gpk_scratch(h, (size_t)S * M * P * sizeof(float), &partial));
-  // D <= 15: distances on the bf16 matrix cores (exact three-way operand split, depth D + 1 <= 16);
-  // D = 16: depth 17, nine fp32 MFMAs
-  hipLaunchKernelGGL(D > 15 ? mm_pick_p<9>(P) : mm_pick_bf16(P), dim3((unsigned)nqb, (unsigned)S), dim3(256), 0, h->stream, X, alpha,
+  // D <= 14: distances on the bf16 matrix cores (exact three-way operand split, depth D + 2 <= 16);
+  // D = 15, 16: depth up to 17, nine fp32 MFMAs
+  hipLaunchKernelGGL(D > 14 ? mm_pick_p<9>(P) : mm_pick_bf16(P), dim3((unsigned)nqb, (unsigned)S), dim3(256), 0, h->stream, X, alpha,
                      (long long)N, D, sc, ctr, Xq, (long long)M, (long long)chunk, (float*)partial);
   GPK_LAUNCH_CHECK(h);
   const int64_t tot = M * P;
