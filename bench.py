@@ -62,10 +62,10 @@ def parse_args(argv=None):
                          "only, RCCL all-gather of the means (strong scaling); gram: the fp64 RBF Gram build at N_train, "
                          "row-sharded over the GPUs with no exchange (SURVEY 8e; strong scaling, GB/s)")
     ap.add_argument("--var-method", default="auto", choices=["auto", "inverse_split", "inverse_split2", "inverse", "solve"],
-                    help="auto = inverse_split: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch on the "
-                         "bf16 matrix pipe with both fp32 operands split exactly into three bf16 parts (fp32 accuracy); "
-                         "inverse: the same launch on the exact-fp32 MFMA; solve: blocked triangular solve chain; inverse_split2: "
-                         "the optional fp16 x 2 split (three products per block, 22-bit products) - not the headline")
+                    help="auto = inverse_split2: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch on the "
+                         "16-bit matrix pipe, every fp32 operand as two round-to-nearest fp16 parts (represented to 2^-24), "
+                         "three products per block, fp32 accumulation; inverse_split: three exact bf16 parts, six products; "
+                         "inverse: the same launch on the exact-fp32 MFMA; solve: blocked triangular solve chain")
     return ap.parse_args(argv)
 
 
@@ -312,7 +312,7 @@ def main():
     c4 = args.workload == "c4"
     if c4:
         args.queries = (1 << 20) // world          # strong scaling: the 1 M queries are split over the ranks
-    method = "inverse_split" if args.var_method == "auto" else args.var_method
+    method = "inverse_split2" if args.var_method == "auto" else args.var_method
     N, M, D, P = args.n_train, args.queries, 9, 3
     X, Y, _ = synthetic_problem(N, 1)
     Yn = (Y - Y.mean(0)) / Y.std(0)
@@ -494,8 +494,9 @@ def main():
         elif method == "inverse_split2":
             key, peak = "k5_split2_kernel", MFMA_BF16_PEAK_TF        # fp16 MFMA: the same rate as bf16
             executed = 3.0 * flops
-            kernel = ("k5_split_kernel<4,2> (V = W K*^T, fp32 operands as 2 fp16 parts, 3 x v_mfma_f32_32x32x16_f16 per "
-                      "32x32x16 block product, fp32 accumulation, fused column-norm epilogue, 1 launch/step)")
+            kernel = ("k5_split_kernel<4,2> (V = W K*^T, fp32 operands as 2 round-to-nearest fp16 parts, 3 x "
+                      "v_mfma_f32_32x32x16_f16 per 32x32x16 block product, fp32 accumulation, fused column-norm epilogue, "
+                      "1 launch/step)")
         else:
             key, peak = ("gemm_kernel_f32_epi1", MFMA_F32_PEAK_TF)
             executed = flops
@@ -536,60 +537,57 @@ def main():
                     "note": "PCIe-inclusive: 10 000 x 9 fp32 queries host->HBM, (10 000 x 6) fp64 results HBM->host"}
         assert np.isfinite(res).all()
 
-    # ---------------------------------------------------------------- extra: the exact-fp32 MFMA form of the same launch
+    # ---------------------------------------------------------------- extras: the other fp32 forms of the same launch
+    # (never the headline; same batch, same factor; each with its own error against the fp64 kernels)
     extras = None
-    if rank == 0 and world == 1 and not c4 and method == "inverse_split" and not args.no_extras:
+    if rank == 0 and world == 1 and not c4 and method == "inverse_split2" and not args.no_extras:
+        extras = {}
         try:
+            dev._Winv.pop("split2", None)
             dev.inverse_factor(True)               # fp32 copy of W (recomputes W on the fp64 MFMA: untimed)
             dev._Winv.pop("f64", None)
-            dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse")
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(3):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                dev.predict_mean_dev(q32, y_mean, y_std, "float32")
-                v32 = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse")
-                b.record()
+
+            def time_form(m):
+                dev.predict_var_dev(q32, kss, 0.0, "float32", m)
                 torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b) * 1e-3)
-            t32 = sorted(ts)[1]
-            extras = {"fp32_mfma_path": {
-                "what": "mean + variance with the variance GEMM on v_mfma_f32_32x32x2_f32 (round 1's headline path; "
-                        "--var-method inverse)",
-                "ms_per_step": t32 * 1e3, "predictions_per_s": M / t32,
-                "fp32_mfma_TFLOPs": float(N) * N * M / t32 / 1e12, "frac_of_fp32_mfma_peak": float(N) * N * M / t32 / 1e12 / MFMA_F32_PEAK_TF,
-                "max_abs_var_diff_vs_timed_path": float(torch.max(torch.abs(v32 * float(y_std[0] ** 2) - out[:M, P].double())))}}
-            # the optional fp16 x 2 split (three products per block instead of six; 22-bit products): never the headline
-            dev.split2_inverse_factor()
+                dev.timing(True)
+                ts = []
+                for _ in range(3):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    dev.predict_mean_dev(q32, y_mean, y_std, "float32")
+                    v = dev.predict_var_dev(q32, kss, 0.0, "float32", m)
+                    b.record()
+                    torch.cuda.synchronize()
+                    ts.append(a.elapsed_time(b) * 1e-3)
+                km = dev.kernel_times(_lib.GPK_TIMED_K5)
+                dev.timing(False)
+                t = sorted(ts)[1]
+                e = float(((torch.sqrt(v) - torch.sqrt(v64)).abs() / torch.sqrt(v64)).max()) if v64 is not None else None
+                return t, float(np.mean(km)), e
+
+            t32, k32, e32 = time_form("inverse")
+            extras["fp32_mfma_path"] = {
+                "what": "mean + variance with the variance GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products; round 1's "
+                        "headline path; --var-method inverse)",
+                "ms_per_step": t32 * 1e3, "predictions_per_s": M / t32, "kernel_ms": k32,
+                "fp32_mfma_TFLOPs": float(N) * N * M / (k32 * 1e-3) / 1e12,
+                "frac_of_fp32_mfma_peak": float(N) * N * M / (k32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                "std_max_rel_err_vs_fp64": e32}
+            dev.split_inverse_factor()
             dev._Winv.pop("f32", None)
-            dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split2")
-            torch.cuda.synchronize()
-            dev.timing(True)
-            ts = []
-            for _ in range(3):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                dev.predict_mean_dev(q32, y_mean, y_std, "float32")
-                v2 = dev.predict_var_dev(q32, kss, 0.0, "float32", "inverse_split2")
-                b.record()
-                torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b) * 1e-3)
-            k2 = dev.kernel_times(_lib.GPK_TIMED_K5)
-            dev.timing(False)
-            t2 = sorted(ts)[1]
-            extras["fp16x2_split_path"] = {
-                "what": "mean + variance with the variance GEMM on v_mfma_f32_32x32x16_f16: fp32 operands as 2 fp16 parts "
-                        "(22 significant bits), products a1 b0 + a0 b1 + a0 b0, fp32 accumulation (--var-method would be "
-                        "'inverse_split2'; optional fast form, not selected by 'auto')",
-                "ms_per_step": t2 * 1e3, "predictions_per_s": M / t2, "kernel_ms": float(np.mean(k2)),
-                "fp16_mfma_TFLOPs": 3.0 * float(N) * N * M / (float(np.mean(k2)) * 1e-3) / 1e12,
-                "std_max_rel_err_vs_fp64": float(((torch.sqrt(v2) - torch.sqrt(v64)).abs() / torch.sqrt(v64)).max())
-                                           if v64 is not None else None,
-                "std_max_rel_err_vs_fp64_of_the_timed_path": parity["std_max_rel_err_vs_fp64"] if parity else None}
-            dev._Winv.pop("split2", None)
+            t3, k3, e3 = time_form("inverse_split")
+            extras["bf16x3_split_path"] = {
+                "what": "mean + variance with the variance GEMM on v_mfma_f32_32x32x16_bf16: fp32 operands as 3 exact bf16 "
+                        "parts, 6 products per block (--var-method inverse_split)",
+                "ms_per_step": t3 * 1e3, "predictions_per_s": M / t3, "kernel_ms": k3,
+                "bf16_mfma_TFLOPs": 6.0 * float(N) * N * M / (k3 * 1e-3) / 1e12,
+                "frac_of_bf16_mfma_peak": 6.0 * float(N) * N * M / (k3 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                "std_max_rel_err_vs_fp64": e3}
+            extras["std_max_rel_err_vs_fp64_of_the_timed_path"] = parity["std_max_rel_err_vs_fp64"] if parity else None
+            dev._Winv.pop("split", None)
         except Exception as e:  # noqa: BLE001 - an extra must never take the headline down
-            extras = {"error": repr(e)} if extras is None else dict(extras, error=repr(e))
+            extras["error"] = repr(e)
 
     if rank == 0:
         total_pred = float(M) * world * args.steps
@@ -611,8 +609,11 @@ def main():
                                      ("; products on the bf16 MFMA pipe from an exact 3-way bf16 split of every fp32 "
                                       "operand (error class of the fp32 MFMA, checked under \"parity\")"
                                       if (method == "inverse_split" and not c4) else
-                                      ("; products on the fp16 MFMA pipe from a 2-way fp16 split (22 significant bits per "
-                                       "operand): the optional fast form" if (method == "inverse_split2" and not c4) else "")),
+                                      ("; products on the fp16 MFMA pipe: every fp32 operand as two round-to-nearest fp16 parts "
+                                       "(a0 + a1 = a to 2^-24, fp32's own unit roundoff), block products a1 b0 + a0 b1 + a0 b0 "
+                                       "(error <= 3 x 2^-24 per product, below the fp32 accumulation error; checked under "
+                                       "\"parity\" and, for all three fp32 forms, under \"extras\")"
+                                       if (method == "inverse_split2" and not c4) else "")),
                        "parallelism": f"query-sharded x{world}, model replicated (every rank fits redundantly)" +
                                       ((", RCCL all-gather of the means" if c4 else ", RCCL all-gather of [mean|var]")
                                        if use_dist else "")},

@@ -218,18 +218,25 @@ int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, co
                               const void* W3, int64_t Np, const float* Xq, int64_t M, double kss, double floor_,
                               float* work, void* work3, double* var);
 
-/* Optional fast form of the same launch at slightly less than fp32 accuracy: fp16 x 2 split, three products per block.
+/* The same launch with an fp16 x 2 operand split, three products per block.
  * gpk_split2: src (dev rows x ld fp32) -> dst (dev, rows * cols * 4 bytes): x * scale = h0 + h1 (+ a remainder below
- * 2^-22 |x|) with h0, h1 fp16, chunk order [row / 4][k16 block][row % 4][half][part]; `scale` is a power of two chosen
+ * 2^-24 |x|) with h0, h1 fp16 rounded to nearest, chunk order [row / 4][k16 block][row % 4][half][part]; `scale` is a power of two chosen
  * by the caller so that max |x * scale| <= 2^15 (it puts the operand at the top of fp16's range; entries more than
  * 2^-12 below the largest lose relative - not absolute - precision).
  * gpk_predict_var_inv_split2: as gpk_predict_var_inv_split with W2 = gpk_split2(fp32 inverse factor, w_scale); K* is
  * scaled by the power of two below 2^15 / sf2 internally; block products are a1 b0 + a0 b1 + a0 b0 on
- * v_mfma_f32_32x32x16_f16 (22 significant bits per product instead of 24, fp32 accumulation): half the matrix-pipe work of
- * the exact split.  Not the default anywhere: for callers (e.g. an MPC confidence gate) to whom a 1e-4 relative error
- * of the standard deviation is immaterial.  work: dev float[Mp * Np]; work2: dev, Mp * Np * 4 bytes; var: dev double[Mp].
+ * v_mfma_f32_32x32x16_f16, fp32 accumulation: half the matrix-pipe work of the bf16 x 3 split.  With round-to-nearest
+ * parts a0 + a1 reproduces a to 2^-24 (fp32's unit roundoff) and the dropped a1 b1 is below 2^-24 |a b|: at most
+ * 3 x 2^-24 per product, below what the fp32 accumulation adds; measured over 31 random models the error of
+ * |W k*|^2 equals that of the exact-fp32 MFMA launch (profiles/r02_fp32_variance_forms_accuracy.log).  The fp32 default
+ * of the Python host side and of gpk_predict.  work: dev float[Mp * Np]; work2: dev, Mp * Np * 4 bytes; var: dev
+ * double[Mp].
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485).                  */
 int gpk_split2(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, double scale, void* dst);
+/* *out (host) = max |A_ij| over the lower triangle of the fp32 matrix A (dev n x lda): what the caller derives the
+ * scale of gpk_split2 from for an inverse factor (scale = the largest power of two with scale * max <= 2^15).
+ * Synchronises.                                                                                                    */
+int gpk_tril_absmax(gpk_handle h, const float* A, int64_t n, int64_t lda, double* out);
 int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
                                const void* W2, double w_scale, int64_t Np, const float* Xq, int64_t M, double kss,
                                double floor_, float* work, void* work2, double* var);
@@ -316,7 +323,7 @@ int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* 
  *   called at src/px4/simple_gp.py:170-177; GaussianProcess.fit, gaussian_process.py:173-201.
  * gpk_predict: Xq host (M x D), mean host (M x P), var host (M x P: per-output VARIANCE, already multiplied by
  *   y_std^2; NULL = means only), all of `dtype` (GPK_F64: double buffers, fp64 kernels; GPK_F32: float buffers, the
- *   fp32 serving kernels - matrix-core mean when admissible, bf16 x 3 split variance).  var_includes_noise != 0:
+ *   fp32 serving kernels - matrix-core mean when admissible, fp16 x 2 split variance).  var_includes_noise != 0:
  *   k** = sf2 + noise, variance clipped at 0 (scikit-learn: Sum.diag, _gpr.py:474-485; take sqrt for its std);
  *   == 0: k** = sf2, floored at 1e-10 (gaussian_process.py:229-233).  Queries are processed in panels.
  *   Replaces: GaussianProcessRegressor.predict, _gpr.py:441-494 (src/px4/simple_gp.py:194, mpc.py:1490-1506);

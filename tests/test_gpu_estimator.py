@@ -423,12 +423,15 @@ def test_baseline_size_properties():
     v64 = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float64", "inverse").cpu().numpy()
     v32 = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float32", "inverse").cpu().numpy()
     vsp = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float32", "inverse_split").cpu().numpy()
+    vs2 = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float32", "inverse_split2").cpu().numpy()
     vau = dev.predict_var_dev(Xq, 1.0 + s, 0.0, "float32", "auto").cpu().numpy()
-    assert np.array_equal(vau, vsp)                     # "auto" is the split launch for fp32
+    assert np.array_equal(vau, vs2)                     # "auto" is the fp16 x 2 split launch for fp32
+    es2 = np.max(np.abs(np.sqrt(vs2) - np.sqrt(v64)) / np.sqrt(v64))
     assert np.all(v64 >= 0.0) and np.all(v64[:8] < 2.0 * s) and np.all(v64[:8] > s)   # prior 1 + s; data explain ~all of it
     e32 = np.max(np.abs(np.sqrt(v32) - np.sqrt(v64)) / np.sqrt(v64))
     esp = np.max(np.abs(np.sqrt(vsp) - np.sqrt(v64)) / np.sqrt(v64))
     assert e32 < 1e-3 and esp < 1e-3 and esp < 2.0 * e32 + 1e-6, (e32, esp)
+    assert es2 < 1e-3 and es2 < 2.0 * e32 + 1e-6, (e32, es2)      # the three fp32 forms: one accuracy class
     if M > 256:                                         # the solve chain (the reference's literal form) on a slice
         vso = dev.predict_var_dev(Xq[:256], 1.0 + s, 0.0, "float64", "solve").cpu().numpy()
         assert np.max(np.abs(vso - v64[:256])) < 1e-9

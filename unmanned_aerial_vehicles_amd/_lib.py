@@ -36,6 +36,7 @@ SIGNATURES = {
     "gpk_import": (_int, [_vp, _dp, _i64, _int, _dp, _dp, _int, _dp, _int, _dbl, _dbl, _dp, _dp]),
     "gpk_model_release": (_int, [_vp]),
     "gpk_split2": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _vp]),
+    "gpk_tril_absmax": (_int, [_vp, _vp, _i64, _i64, C.POINTER(C.c_double)]),
     "gpk_predict_var_inv_split2": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _vp, _dbl, _i64, _vp, _i64, _dbl, _dbl, _vp,
                                           _vp, _vp]),
     "gpk_set_option": (_int, [_vp, C.c_char_p, _int]),

@@ -106,6 +106,17 @@ __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ s
   d[1] = __builtin_bit_cast(V16, p1);
 }
 
+// max |A_ij| over the lower triangle (j <= i) of a square fp32 matrix: one row per workgroup, one atomic per row
+// (the bit pattern of a non-negative float orders like the value)
+__global__ __launch_bounds__(256) void tril_absmax_kernel(const float* __restrict__ A, long long n, long long lda,
+                                                          unsigned* __restrict__ out) {
+  const long long i = blockIdx.x;
+  float m = 0.f;
+  for (long long j = threadIdx.x; j <= i; j += 256) m = fmaxf(m, fabsf(A[i * lda + j]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 struct SParams {
   const char* A;        // W, split layout, Np rows
   const char* B;        // Kq, split layout, Mp rows
@@ -561,6 +572,22 @@ extern "C" int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t 
   hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, (long long)rows,
                      (long long)cols, (long long)ld, (V16*)dst);
   GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_tril_absmax(gpk_handle h, const float* A, int64_t n, int64_t lda, double* out) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, A && out && n >= 1 && lda >= n && n < (1ll << 31), "tril_absmax: bad argument");
+  unsigned* d = reinterpret_cast<unsigned*>(h->d_small);
+  GPK_CHECK_HIP(h, hipMemsetAsync(d, 0, sizeof(unsigned), h->stream));
+  hipLaunchKernelGGL(tril_absmax_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, A, (long long)n, (long long)lda, d);
+  GPK_LAUNCH_CHECK(h);
+  unsigned bits = 0;
+  GPK_CHECK_HIP(h, hipMemcpyAsync(&bits, d, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  float f;
+  memcpy(&f, &bits, sizeof f);
+  *out = (double)f;
   return GPK_OK;
 }
 

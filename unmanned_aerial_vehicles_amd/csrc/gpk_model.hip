@@ -22,7 +22,8 @@ struct gpk_model {
   bool has_W = false;
   // fp32 serving copies (built on the first fp32 predict)
   float *Xf = nullptr, *alphaf = nullptr;
-  void* W3 = nullptr;            // exact bf16 x 3 split of W (gpk_split3)
+  void* W3 = nullptr;            // fp16 x 2 split of W (gpk_split2) ...
+  double w_scale = 1.0;          // ... and the power of two it was scaled by
   // scratch of gpk_lml: a second factorisation that leaves the fitted one alone
   double *sK = nullptr, *sW = nullptr, *sKinv = nullptr, *sT = nullptr, *swinv = nullptr, *salpha = nullptr;
   // query staging
@@ -239,12 +240,17 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
     GPK_LAUNCH_CHECK(h);
   }
   if (f32 && var && !m->W3) {
-    // fp32 serving form of K5: W as three exact bf16 parts per entry (the fp32 copy is only the source of the split)
+    // fp32 serving form of K5: W as two fp16 parts per entry (the fp32 copy is only the source of the split)
     float* Wf = nullptr;
     GPK_CHECK_HIP(h, hipMalloc((void**)&Wf, (size_t)m->Np * m->Np * sizeof(float)));
     int rc = gpk_tril_to_f32(h, m->W, m->Np, m->Np, Wf, m->Np);
-    if (rc == GPK_OK) rc = hipMalloc(&m->W3, (size_t)m->Np * m->Np * 6) == hipSuccess ? GPK_OK : GPK_HIP_ERROR;
-    if (rc == GPK_OK) rc = gpk_split3(h, Wf, m->Np, m->Np, m->Np, m->W3);
+    double wmax = 0.0;
+    if (rc == GPK_OK) rc = gpk_tril_absmax(h, Wf, m->Np, m->Np, &wmax);
+    if (rc == GPK_OK) {
+      m->w_scale = std::ldexp(1.0, (int)std::floor(std::log2(32768.0 / (wmax > 1e-300 ? wmax : 1e-300))));
+      rc = hipMalloc(&m->W3, (size_t)m->Np * m->Np * 4) == hipSuccess ? GPK_OK : GPK_HIP_ERROR;
+    }
+    if (rc == GPK_OK) rc = gpk_split2(h, Wf, m->Np, m->Np, m->Np, m->w_scale, m->W3);
     if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
     (void)hipFree(Wf);
     GPK_TRY(rc);
@@ -258,7 +264,7 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
   GPK_TRY(grow(h, &m->mean, &m->mean_bytes, (size_t)panel * P * es));
   if (var) {
     GPK_TRY(grow(h, &m->work, &m->work_bytes, (size_t)m->Np * panel * es));
-    if (f32) GPK_TRY(grow(h, &m->work3, &m->work3_bytes, (size_t)m->Np * panel * 6));
+    if (f32) GPK_TRY(grow(h, &m->work3, &m->work3_bytes, (size_t)m->Np * panel * 4));
     GPK_TRY(grow(h, (void**)&m->var, &m->var_bytes, (size_t)panel * sizeof(double) + (size_t)panel * P * es + GPK_MAX_P * sizeof(double)));
   }
   double* d_ystd = nullptr;
@@ -281,8 +287,8 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
     GPK_CHECK_HIP(h, hipMemcpyAsync((char*)mean + (size_t)m0 * P * es, m->mean, (size_t)mc * P * es, hipMemcpyDeviceToHost, h->stream));
     if (var) {
       if (f32)
-        GPK_TRY(gpk_predict_var_inv_split(h, m->Xf, m->N, D, m->ls, m->sf2, m->W3, m->Np, (const float*)m->q, mc, kss,
-                                          floor_, (float*)m->work, m->work3, m->var));
+        GPK_TRY(gpk_predict_var_inv_split2(h, m->Xf, m->N, D, m->ls, m->sf2, m->W3, m->w_scale, m->Np, (const float*)m->q, mc,
+                                           kss, floor_, (float*)m->work, m->work3, m->var));
       else
         GPK_TRY(gpk_predict_var_inv(h, GPK_F64, m->X, m->N, D, m->ls, m->sf2, m->W, m->Np, m->Np, m->q, mc, kss, floor_,
                                     m->work, m->var));

@@ -461,13 +461,13 @@ class DeviceGP:
         if "split2" not in self._Winv:
             had_f32 = "f32" in self._Winv
             Wf = self.inverse_factor(True)
-            # largest |W_ij| over the lower triangle (what lies right of the zero band is not part of W), block by block
-            wmax = 0.0
-            for r0 in range(0, self.Np, 4096):
-                r1 = min(self.Np, r0 + 4096)
-                wmax = max(wmax, float(torch.tril(Wf[r0:r1, :r1], diagonal=r0).abs().max()))
-            scale = 2.0 ** int(np.floor(np.log2(32768.0 / max(wmax, 1e-300))))
             be = self.be
+            # largest |W_ij| over the lower triangle (what lies right of the zero band is not part of W)
+            wmax = C.c_double(0.0)
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_tril_absmax(be.h, _p(Wf), self.Np, self.Np, C.byref(wmax)))
+            scale = 2.0 ** int(np.floor(np.log2(32768.0 / max(wmax.value, 1e-300))))
             W2 = be.empty((self.Np * self.Np * 4,), torch.uint8)
             with be.lock:
                 be.bind_stream()
@@ -490,10 +490,12 @@ class DeviceGP:
     # largest) once per alpha; the estimator routes a model with c * A2 above 1e-4 to the fp64 kernels (gpr.py).
     FP32_MEAN_ERR_PER_AMP = {"mfma": 4.0e-7, "valu": 9.0e-7}
     FP32_MEAN_TOL = 1e-4
-    # Variance: |W k*|^2 in fp32 is off by ~4e-6 kss (measured, N = 10^4 .. 6.5 10^4), i.e. the relative error of the
-    # standard deviation is ~2e-6 kss / var: queries whose variance is below this fraction of the prior's are
-    # recomputed in fp64 (2.5x margin to the 1e-3 bar).
-    FP32_VAR_RECHECK_FRACTION = 5e-3
+    # Variance: |W k*|^2 in fp32 is off by 2e-7 .. 4e-5 of kss, growing as the noise shrinks (31 random models, all three
+    # fp32 forms alike: profiles/r02_fp32_variance_forms_accuracy.log), i.e. the relative error of the standard
+    # deviation is that over 2 var / kss: queries whose variance is below this fraction of the prior's - possible only
+    # next to training points of a model with noise << sf2, which is also where the error is largest - are recomputed
+    # in fp64.
+    FP32_VAR_RECHECK_FRACTION = 1e-2
 
     def fp32_mean_amplification(self):
         """A2 (see above) on <= 1024 evenly spaced training rows: two fp64 K4 launches - the second with the squared
@@ -521,16 +523,18 @@ class DeviceGP:
         method "solve": V = L^-1 K*^T by the blocked triangular solve (the reference's
         solve_triangular; a chain of 2 Np/128 - 1 GEMM launches); "inverse": |W k*|^2 with the
         explicit inverse factor W = L^-1, formed once per factorisation, in ONE fused GEMM launch (fp64 MFMA, or
-        the exact-fp32 MFMA); "inverse_split" (fp32 only): the same launch on the bf16 matrix pipe with both fp32
-        operands split exactly into three bf16 parts (fp32 accuracy, 1.5x the fp32 MFMA's speed); "auto":
-        "inverse" for fp64, "inverse_split" for fp32.  "inverse_split2" (fp32 only, never chosen automatically): the
-        same launch with an fp16 x 2 operand split and three products per block - 22 instead of 24 significant bits per
-        product, half the matrix-pipe work."""
+        the exact-fp32 MFMA).  fp32 only - the same launch with the products on the 16-bit matrix pipe (fp32
+        accumulation, operands represented to fp32's own unit roundoff): "inverse_split2": every fp32 operand as two
+        round-to-nearest fp16 parts (a0 + a1 = a to 2^-24), block products a1 b0 + a0 b1 + a0 b0 (error <= 3 x 2^-24
+        per product, below the fp32 accumulation error; measured over 31 random models: the same |W k*|^2 error as the
+        exact-fp32 MFMA, profiles/r02_fp32_variance_forms_accuracy.log; 2.6x its speed); "inverse_split": three bf16
+        parts (exact), six products per block (1.5x the fp32 MFMA's speed).  "auto": "inverse" for fp64,
+        "inverse_split2" for fp32."""
         torch = _torch()
         assert self.factored
         f32 = dtype in ("float32", np.float32, torch.float32)
         if method == "auto":
-            method = "inverse_split" if f32 else "inverse"
+            method = "inverse_split2" if f32 else "inverse"
         if method not in ("solve", "inverse", "inverse_split", "inverse_split2"):
             raise ValueError("method must be 'auto', 'solve', 'inverse', 'inverse_split' or 'inverse_split2'")
         if method in ("inverse_split", "inverse_split2") and not f32:
