@@ -20,7 +20,9 @@
  *     gpk_synchronize() waits.  Functions with a host output parameter synchronise.
  *   - Return codes: GPK_OK, GPK_NOT_PD (Cholesky pivot <= 0; 1-based row in the
  *     error string and *info), GPK_BAD_ARG, GPK_HIP_ERROR.  gpk_last_error() gives text.
- *   - No global state; one handle per GPU / host thread.
+ *   - No global state; one handle per GPU / host thread.  Kernels launch on, and allocations come from, the calling
+ *     thread's current HIP device: gpk_set_stream (and every allocation the handle makes) selects the handle's device,
+ *     so a caller that drives handles on several GPUs from one thread calls gpk_set_stream before each group of calls.
  */
 #ifndef GPK_H
 #define GPK_H

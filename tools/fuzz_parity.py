@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: random (N, D, P, M, hyper-parameters, ARD or isotropic, predict dtype, variance
-method) through the estimator seam against the CPU oracle.  Not part of the test suite (the suite pins fixed
-cases); this is the tool that hunts for size-dependent indexing mistakes (tile edges, zero band, super-tile
-gating, ragged query batches).  `FUZZ_CASES` (default 150), `FUZZ_SEED`, `FUZZ_MAX_N` (default 3000)."""
+method) through the estimator seam against the CPU oracle, with the documented tolerances as pass bars.  The long
+form of tests/test_gpu_fuzz.py (which runs 54 fixed-seed cases in the suite): this is the tool that hunts for
+size-dependent indexing mistakes (tile edges, zero band, super-tile gating, ragged query batches).  `FUZZ_CASES` (default 150), `FUZZ_SEED`, `FUZZ_MAX_N` (default 3000)."""
 import os
 import sys
 import time
@@ -42,9 +42,7 @@ for c in range(cases):
     noise = float(np.exp(rng.uniform(np.log(1e-3), np.log(0.3))))
     normalize = bool(rng.random() < 0.5)
     pd = "float32" if rng.random() < 0.4 else "float64"
-    if pd == "float32":          # fp32 serving is for well-conditioned models: its error grows with sf2 N / noise
-        noise = max(noise, 0.02)
-    vm = str(rng.choice(["auto", "inverse", "solve"] + (["inverse_split"] if pd == "float32" else [])))
+    vm = str(rng.choice(["auto", "inverse", "solve"] + (["inverse_split", "inverse_split2"] if pd == "float32" else [])))
     X = rng.standard_normal((N, D))
     Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
     Xq = rng.standard_normal((M, D)) * rng.choice([0.5, 1.0, 2.0])
@@ -75,7 +73,8 @@ for c in range(cases):
     # fp32 mean: every term K*_mj alpha_j carries a few fp32 roundings, so the bound scales with sum_j |K*_mj alpha_j|
     cond = float(np.max(np.abs(O.rbf_cross(Xq, st.X, st.length_scale, st.signal_variance)) @ np.abs(st.alpha) * st.y_std) / max(np.max(np.abs(om)), 1e-300))
     # (fp32 kernel entries carry the rounding of the squared distance, ~1e-7 * d^2 in the exponent: a few 1e-6 relative)
-    tol_m, tol_s = (max(2e-4, 5e-6 * cond), 2e-3) if pd == "float32" else (1e-8, 1e-7)
+    # the documented bars; fp32 with the serving gates of the estimator active
+    tol_m, tol_s = (1e-4, 1e-3) if pd == "float32" else (1e-8, 1e-7)
     ok = (e_mean < tol_m and e_std < tol_s and e_lml < 1e-9 and abs(lml2 - lml) <= 1e-9 * abs(lml) and not (e_grad > 1e-6)
           and np.array_equal(np.asarray(mean_only).reshape(M, -1), mean))
     if not ok:

@@ -64,6 +64,9 @@ extern "C" const char* gpk_last_error(gpk_handle h) { return h ? h->err.c_str() 
 extern "C" int gpk_set_stream(gpk_handle h, void* stream) {
   if (!h) return GPK_BAD_ARG;
   hipStream_t want = (stream == GPK_OWN_STREAM) ? h->own_stream : (hipStream_t)stream;
+  // launches and allocations of the calls that follow go to the calling thread's current device: make that the
+  // handle's (two handles on two GPUs in one process; the Python side calls this before every group of calls)
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
   if (want == h->stream) return GPK_OK;
   // work queued on the old stream must finish before later calls may reuse the handle's scratch
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
@@ -150,6 +153,7 @@ extern "C" int gpk_synchronize(gpk_handle h) {
 
 int gpk_scratch(gpk_handle h, size_t bytes, void** out) {
   if (bytes > h->scratch_bytes) {
+    GPK_CHECK_HIP(h, hipSetDevice(h->device));
     // growing: wait for users of the old block, then replace it
     GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
     if (h->scratch) GPK_CHECK_HIP(h, hipFree(h->scratch));
@@ -213,6 +217,7 @@ extern "C" int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64
 // Grow the serving staging blocks (pinned, device-mapped host block; device work block) to at least these sizes.
 static int serve_reserve(gpk_handle h, size_t host_need, size_t dev_need) {
   if (host_need <= h->serve_host_bytes && dev_need <= h->serve_dev_bytes) return GPK_OK;
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   if (host_need > h->serve_host_bytes) {
     if (h->serve_host) GPK_CHECK_HIP(h, hipHostFree(h->serve_host));
