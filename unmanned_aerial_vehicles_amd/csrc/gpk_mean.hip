@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void mean_mfma_kernel(const float* __restri
         xt[d][t] = -2.f * u;
       }
       xt[D][t] = tn;
-      if (D + 1 < 2 * KP) xt[D + 1][t] = 0.f;
+      for (int k = D + 1; k < 2 * KP; ++k) xt[k][t] = 0.f;      // (D = 15: two unused components, not one)
 #pragma unroll
       for (int p = 0; p < PP; ++p) al[p][t] = in ? alpha[j * PP + p] : 0.f;
     }
