@@ -45,9 +45,16 @@ for form in [int(f) for f in os.environ.get("FORMS", "1,2,1,2").split(",")]:
     print(f"form {form}: kernel {np.mean(ms):8.2f} ms (min {np.min(ms):.2f} max {np.max(ms):.2f}) = "
           f"{6.0 * N * N * M / np.mean(ms) / 1e9:7.1f} TF bf16, {M / np.mean(ms) * 1e3 / 1e3:6.1f} k pred/s kernel-only; "
           f"std err vs fp64 {err:.2e}", flush=True)
-if os.environ.get("SPLIT2", "1") == "1" and os.environ.get("ZERO") != "1":
-    dev.split2_inverse_factor()
-    dev._Winv.pop("split", None)
+if os.environ.get("SPLIT2", "1") == "1":
+    if os.environ.get("ZERO") == "1":
+        dev.ls = np.full(9, 2.0)                 # (split2_inverse_factor needs the real W once more)
+        dev._Winv.pop("split", None)
+        dev.split2_inverse_factor()
+        dev._Winv["split2"][0].zero_()
+        dev.ls = np.full(9, 1e-3)
+    else:
+        dev.split2_inverse_factor()
+        dev._Winv.pop("split", None)
     dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
     dev.timing(True)
     for _ in range(reps):

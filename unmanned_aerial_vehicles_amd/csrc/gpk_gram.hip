@@ -304,6 +304,66 @@ __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, l
   }
 }
 
+// ---- K* written straight into the fp16 x 2 split layout of the variance launch ------------------------
+// Kq[q][j] = sf2 exp(-0.5 |xq_q - x_j|^2) (query-major, j = training point = the k index of V = W Kq^T), zero in the
+// padding, never stored as fp32: a lane computes the eight values of one (query, k-half) and writes their two fp16
+// parts as two adjacent 16-byte chunks of the layout [q / 4][k16 block][q % 4][half][part] (gpk_split2) - the
+// separate fp32 panel (2.65 GB at the headline shape) and the pass that split it (2.65 GB read + 2.65 GB written) are
+// gone.  Same arithmetic per entry as cross_t_kernel (exact differences of the length-scale-divided coordinates,
+// FMA accumulation, exp_neg), then x * scale = h0 + h1 as in split2_kernel.
+// Workgroup: 64 queries x 128 training points (8 k16 blocks); a wave instruction writes 2 KiB of contiguous output.
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+template <int DD>   // DD = D rounded up to a multiple of 4 (query coordinates in registers)
+__global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restrict__ Xq, long long M,
+                                                           const float* __restrict__ X, long long N, int D, LsArr ls,
+                                                           float sf2, float scale, u4_t* __restrict__ dst, long long Np) {
+  // 64 queries (four quads per wave, one after the other) x 128 training points per workgroup: the staged points are
+  // reused 64 times
+  __shared__ __attribute__((aligned(16))) float xs[DD][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long j0 = (long long)blockIdx.x * 128, q0 = (long long)blockIdx.y * 64;
+  for (int e = tid; e < 128 * DD; e += 256) {
+    const int d = e >> 7, i = e & 127;
+    const long long gj = j0 + i;
+    xs[d][i] = (d < D && gj < N) ? X[gj * D + d] / (float)ls.v[d] : 0.f;
+  }
+  __syncthreads();
+  const int qq = (lane >> 1) & 3, kb = lane >> 3, hh = lane & 1;
+  const int kbase = 16 * kb + 8 * hh;
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const long long quad = (q0 >> 2) + 4 * wave + t, q = 4 * quad + qq;
+    float xq[DD];
+#pragma unroll
+    for (int d = 0; d < DD; ++d) xq[d] = (d < D && q < M) ? Xq[q * D + d] / (float)ls.v[d] : 0.f;
+    float d2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d2[i] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+      const float4 lo = *reinterpret_cast<const float4*>(&xs[d][kbase]), hi = *reinterpret_cast<const float4*>(&xs[d][kbase + 4]);
+      const float b[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float df = xq[d] - b[i]; d2[i] = __builtin_fmaf(df, df, d2[i]); }
+    }
+    h8_t p0, p1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float val = sf2 * exp_neg(-0.5f * d2[i]);
+      if (q >= M || j0 + kbase + i >= N) val = 0.f;
+      const float x = val * scale;
+      const _Float16 h0 = (_Float16)x;
+      p0[i] = h0;
+      p1[i] = (_Float16)(x - (float)h0);
+    }
+    // chunk index: (((q / 4) * (Np / 16) + k16 block) * 4 + q % 4) * 4 + half * 2 + part
+    u4_t* o = dst + (((quad * (Np >> 4) + (j0 >> 4) + kb) * 4 + qq) * 4 + hh * 2);
+    o[0] = __builtin_bit_cast(u4_t, p0);
+    o[1] = __builtin_bit_cast(u4_t, p1);
+  }
+}
+
 // ---- K4: fused posterior mean ---------------------------------------------------------------------
 // One thread owns QPT queries (coordinates and output accumulators in registers); training rows
 // [x_j / ls (16 slots) | alpha_j (16 slots)] are staged through LDS with a fixed 32-element stride and
@@ -629,6 +689,23 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
   else { if (stream_nt) GPK_GRAM_LAUNCH(float, true); else GPK_GRAM_LAUNCH(float, false); }
   gpk_time_end(h);
 #undef GPK_GRAM_LAUNCH
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+// Kq (gpk_padded(M) x Np) in the gpk_split2 layout, from fp32 coordinates (internal: gpk_predict_var_inv_split2)
+int gpk_cross_split2(gpk_handle h, const float* Xq, int64_t M, const float* X, int64_t N, int D, const double* ls,
+                     double sf2, double scale, void* dst) {
+  GPK_REQUIRE(h, Xq && X && dst && M >= 1 && N >= 1 && D >= 1 && D <= DCH, "cross_split2: bad argument");
+  const int64_t Np = gpk_padded(N), Mp = gpk_padded(M);
+  LsArr l;
+  GPK_TRY(fill_ls(h, ls, D, l));
+  GPK_REQUIRE(h, Mp / 64 < 65536, "cross_split2: at most 2^22 queries per call");
+  const dim3 grid((unsigned)(Np / 128), (unsigned)(Mp / 64));
+#define GPK_CS2(DD) hipLaunchKernelGGL(cross_split2_kernel<DD>, grid, dim3(256), 0, h->stream, Xq, (long long)M, X, (long long)N, D, l, \
+                                       (float)sf2, (float)scale, (u4_t*)dst, (long long)Np)
+  if (D <= 4) GPK_CS2(4); else if (D <= 8) GPK_CS2(8); else if (D <= 12) GPK_CS2(12); else GPK_CS2(16);
+#undef GPK_CS2
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }

@@ -171,6 +171,9 @@ int gpk_small_predict(gpk_handle h, int B, const double* const* X, const double*
                       const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
                       const double* Xq, int64_t M, double* work, double* mean_out, double* var_out);
 
+// K* straight into the fp16 x 2 split layout (gpk_gram.hip); D <= 16
+int gpk_cross_split2(gpk_handle h, const float* Xq, int64_t M, const float* X, int64_t N, int D, const double* ls,
+                     double sf2, double scale, void* dst);
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out);
 int gpk_colsum_finalize(gpk_handle h, const double* partial, int S, int64_t Mp, int64_t M, double kss, double floor_,

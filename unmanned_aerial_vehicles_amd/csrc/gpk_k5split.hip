@@ -619,8 +619,13 @@ extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t 
   GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 4 * 128 < (1ll << 31), "predict_var_inv_split2: size too large");
   // K* in (0, sf2]: the power of two that puts sf2 just below 2^15
   const double k_scale = std::ldexp(1.0, 14 - (int)std::floor(std::log2(sf2)));
-  GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
-  GPK_TRY(gpk_split2(h, work, Mp, Np, Np, k_scale, work2));
+  if (D <= 16 && Mp / 64 < 65536) {
+    // K* computed and written in split form in one pass (`work` stays unused)
+    GPK_TRY(gpk_cross_split2(h, Xq, M, X, N, D, ls, sf2, k_scale, work2));
+  } else {
+    GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
+    GPK_TRY(gpk_split2(h, work, Mp, Np, Np, k_scale, work2));
+  }
   const int wr = (Np % 256 == 0) ? 4 : 2;
   const int ntmT = (int)(Np / (64 * wr)), gsz = wr == 2 ? 64 : 32;
   void* partial = nullptr;
