@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, l
 // Workgroup: 64 queries x 128 training points (8 k16 blocks); a wave instruction writes 2 KiB of contiguous output.
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-template <int DD>   // DD = D rounded up to a multiple of 4 (query coordinates in registers)
+template <int DD>   // DD = D (query coordinates in registers; one instantiation per feature count)
 __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restrict__ Xq, long long M,
                                                            const float* __restrict__ X, long long N, int D, LsArr ls,
                                                            float sf2, float scale, u4_t* __restrict__ dst, long long Np) {
@@ -331,12 +331,22 @@ __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restri
   __syncthreads();
   const int qq = (lane >> 1) & 3, kb = lane >> 3, hh = lane & 1;
   const int kbase = 16 * kb + 8 * hh;
-#pragma unroll 1
+  // the four quads' coordinates up front (one round of loads in flight), divided by the length-scales as everywhere
+  float xqa[4][DD];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const long long q = 4 * ((q0 >> 2) + 4 * wave + t) + qq;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) xqa[t][d] = q < M ? Xq[q * DD + d] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int d = 0; d < DD; ++d) xqa[t][d] = xqa[t][d] / (float)ls.v[d];
+#pragma unroll
   for (int t = 0; t < 4; ++t) {
     const long long quad = (q0 >> 2) + 4 * wave + t, q = 4 * quad + qq;
-    float xq[DD];
-#pragma unroll
-    for (int d = 0; d < DD; ++d) xq[d] = (d < D && q < M) ? Xq[q * D + d] / (float)ls.v[d] : 0.f;
+    const float (&xq)[DD] = xqa[t];
     float d2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) d2[i] = 0.f;
@@ -702,9 +712,12 @@ int gpk_cross_split2(gpk_handle h, const float* Xq, int64_t M, const float* X, i
   GPK_TRY(fill_ls(h, ls, D, l));
   GPK_REQUIRE(h, Mp / 64 < 65536, "cross_split2: at most 2^22 queries per call");
   const dim3 grid((unsigned)(Np / 128), (unsigned)(Mp / 64));
-#define GPK_CS2(DD) hipLaunchKernelGGL(cross_split2_kernel<DD>, grid, dim3(256), 0, h->stream, Xq, (long long)M, X, (long long)N, D, l, \
-                                       (float)sf2, (float)scale, (u4_t*)dst, (long long)Np)
-  if (D <= 4) GPK_CS2(4); else if (D <= 8) GPK_CS2(8); else if (D <= 12) GPK_CS2(12); else GPK_CS2(16);
+#define GPK_CS2(DD) case DD: hipLaunchKernelGGL(cross_split2_kernel<DD>, grid, dim3(256), 0, h->stream, Xq, (long long)M, X, (long long)N, D, \
+                                                l, (float)sf2, (float)scale, (u4_t*)dst, (long long)Np); break
+  switch (D) {
+    GPK_CS2(1); GPK_CS2(2); GPK_CS2(3); GPK_CS2(4); GPK_CS2(5); GPK_CS2(6); GPK_CS2(7); GPK_CS2(8);
+    GPK_CS2(9); GPK_CS2(10); GPK_CS2(11); GPK_CS2(12); GPK_CS2(13); GPK_CS2(14); GPK_CS2(15); GPK_CS2(16);
+  }
 #undef GPK_CS2
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
