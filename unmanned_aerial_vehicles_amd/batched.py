@@ -241,7 +241,9 @@ class BatchedARDGP:
         for m in self.models:
             m._ensure_device()
         be = get_backend(self.device)
-        f32 = self.predict_dtype == "float32"
+        # fp32 serving is gated as in the estimator (DeviceGP, "fp32 serving gates"): if any model's fp32 mean would leave
+        # the stated 1e-4, the whole fused call runs on the fp64 kernels
+        f32 = self.predict_dtype == "float32" and all(m._dev.fp32_mean_ok() for m in self.models)
         tdt = torch.float32 if f32 else torch.float64
         comps = [m.kernel_.components() for m in self.models]
         D = m0.n_features_in_
