@@ -349,6 +349,32 @@ int gpk_import(gpk_handle h, const double* X, int64_t N, int D, const double* L,
                const double* ls, int n_ls, double sf2, double noise, const double* y_mean, const double* y_std);
 int gpk_model_release(gpk_handle h);
 
+/* ---- composite calls for B (<= GPK_MAX_BATCH) single-output models on shared inputs ----------------------------
+ * The per-axis layout of src/px4/gp_trainer.py:139-179 (one scalar GP per residual component, each with its own ARD
+ * length-scales and noise, all on the same X) as one object behind the handle, next to - and independent of - the
+ * single model of gpk_fit.  HOST pointers in and out, fp64.
+ * gpk_fit_batched: X host (N x D); Y host (N x B), column b = targets of model b; ls host (B x n_ls), n_ls = 1 or D;
+ *   sf2, noise: host double[B]; jitter and normalize_y as in gpk_fit, shared.  One Gram launch per model, then ONE
+ *   batched launch chain for the B factorisations, inverse factors and alpha solves (gpk_batch_begin).  info: host
+ *   int[B], 0 or the 1-based index of model b's first non-positive pivot; if any is non-zero the call returns
+ *   GPK_NOT_PD and the batch is not usable for prediction.
+ *   Replaces: the loop over outputs of GPTrainer.train_gp_models at fixed theta, gp_trainer.py:139-179 (six times
+ *   sklearn/gaussian_process/_gpr.py:271-282,343-364).
+ * gpk_predict_batched: Xq host (M x D); mean host (M x B); var host (M x B: variances in target units, NULL = means
+ *   only); var_includes_noise as in gpk_predict.  Up to 32 queries (N <= 16384) take gpk_predict_host_multi (one call,
+ *   two launches for all models); larger batches one fused mean launch (gpk_predict_mean_multi) and one variance launch
+ *   per model and panel.  Replaces: PreTrainedGP.predict_residual's loop, src/px4/pretrained_gp.py:52-98.
+ * gpk_lml_batched: thetas == NULL: lml[b] = the fitted models' log-marginal likelihoods.  Otherwise thetas host
+ *   (B x n_theta), row b = log [ls (1 or D values), noise] of model b: lml host double[B] and, if grad != NULL, grad
+ *   host (B x n_theta), from one batched launch chain on scratch buffers (BASELINE configuration 5: the
+ *   hyper-parameter step of all per-axis models at once).  A model whose trial matrix is not positive definite gets
+ *   lml = -inf, grad = 0.  Replaces: B evaluations of log_marginal_likelihood, _gpr.py:537-652.
+ * gpk_model_release frees this object too.                                                                         */
+int gpk_fit_batched(gpk_handle h, int B, const double* X, int64_t N, int D, const double* Y, const double* ls, int n_ls,
+                    const double* sf2, const double* noise, double jitter, int normalize_y, int* info);
+int gpk_predict_batched(gpk_handle h, const double* Xq, int64_t M, double* mean, double* var, int var_includes_noise);
+int gpk_lml_batched(gpk_handle h, const double* thetas, int n_theta, double* lml, double* grad);
+
 /* ---- building block: whole-tile GEMM on the matrix cores ---------------------------------------
  * C[m x n] = alpha * opA(A) * opB(B)^T + beta * C, m and n multiples of 128, k a multiple of 16
  * (fp64) / 32 (fp32).  ta == 0: A stored (m x k) with k contiguous; ta == 1: A stored (k x m).

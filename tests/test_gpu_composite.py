@@ -85,3 +85,137 @@ def test_composite_calls_against_oracle(N, D, P, M, ard):
         assert lib.gpk_predict(h, Xq.ctypes.data_as(C.c_void_p), 4, mean.ctypes.data_as(C.c_void_p), None, _lib.GPK_F64, 1) == _lib.GPK_BAD_ARG
     finally:
         lib.gpk_destroy(h)
+
+
+@pytest.mark.parametrize("N,D,B,ard", [(301, 10, 6, True), (1500, 9, 3, True), (640, 4, 2, False), (130, 16, 8, True)])
+def test_batched_composite_calls_against_oracle(N, D, B, ard):
+    """gpk_fit_batched / gpk_predict_batched / gpk_lml_batched: B per-axis models with their own hyper-parameters on
+    shared inputs (gp_trainer.py:139-179) - odd N (row stride padding), both predict routes (<= 32 rows: one call for all
+    models; panels beyond), LML values and gradients at trial thetas, a trial point that is not positive definite."""
+    from unmanned_aerial_vehicles_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7 * N + B)
+    X = rng.standard_normal((N, D))
+    Y = np.ascontiguousarray(np.sin(X @ rng.standard_normal((D, B))) * (1.0 + np.arange(B)) + 0.1 * rng.standard_normal((N, B)))
+    n_ls = D if ard else 1
+    ls = np.ascontiguousarray(np.exp(rng.uniform(-0.3, 0.5, (B, n_ls))) * np.sqrt(D) / 1.5)
+    sf2 = np.ascontiguousarray(np.exp(rng.uniform(-0.5, 0.5, B)))
+    noise = np.ascontiguousarray(np.exp(rng.uniform(np.log(0.01), np.log(0.2), B)))
+    jitter = 1e-6
+    sts = [O.fit_fixed(X, Y[:, b], ls[b] if ard else float(ls[b, 0]), sf2[b], noise[b], jitter, True) for b in range(B)]
+    h = C.c_void_p()
+    assert lib.gpk_create(C.byref(h), 0) == _lib.GPK_OK
+    try:
+        def ok(rc):
+            assert rc == _lib.GPK_OK, lib.gpk_last_error(h).decode()
+        ok(lib.gpk_set_stream(h, C.c_void_p(-1)))
+        info = (C.c_int * B)()
+        ok(lib.gpk_fit_batched(h, B, _dp(X), N, D, _dp(Y), _dp(ls), n_ls, _dp(sf2), _dp(noise), jitter, 1, info))
+        assert not any(info)
+        lml = np.empty(B)
+        ok(lib.gpk_lml_batched(h, None, 0, _dp(lml), None))
+        assert relerr(lml, np.array([O.log_marginal_likelihood(s) for s in sts])) < 1e-10
+        for M in (1, 25, 32, 33, 700):
+            Xq = np.ascontiguousarray(rng.standard_normal((M, D)) * 1.1)
+            mean, var = np.empty((M, B)), np.empty((M, B))
+            ok(lib.gpk_predict_batched(h, _dp(Xq), M, _dp(mean), _dp(var), 1))
+            mean_only = np.empty((M, B))
+            ok(lib.gpk_predict_batched(h, _dp(Xq), M, _dp(mean_only), None, 1))
+            assert np.array_equal(mean_only, mean)
+            vpk = np.empty((M, B))
+            ok(lib.gpk_predict_batched(h, _dp(Xq), M, _dp(mean_only), _dp(vpk), 0))        # package convention
+            for b in range(B):
+                om, os_ = O.predict(sts[b], Xq, return_std=True)
+                assert relerr(mean[:, b], om.ravel()) < 1e-8 and relerr(np.sqrt(var[:, b]), os_.ravel()) < 1e-8
+                _, op = O.predict(sts[b], Xq, return_std=True, diag_includes_noise=False)
+                assert relerr(np.sqrt(vpk[:, b]), np.maximum(op.ravel(), 1e-5 * sts[b].y_std)) < 1e-7
+        # trial hyper-parameters: values and gradients of all models from one chain
+        thetas = np.ascontiguousarray(np.log(np.c_[ls, noise]) + rng.uniform(-0.3, 0.3, (B, n_ls + 1)))
+        grad = np.zeros_like(thetas)
+        ok(lib.gpk_lml_batched(h, _dp(thetas), n_ls + 1, _dp(lml), _dp(grad)))
+        lml_only = np.empty(B)
+        ok(lib.gpk_lml_batched(h, _dp(thetas), n_ls + 1, _dp(lml_only), None))
+        for b in range(B):
+            lsb, nb = np.exp(thetas[b, :n_ls]), float(np.exp(thetas[b, n_ls]))
+            st = O.fit_fixed(X, Y[:, b], lsb if ard else float(lsb[0]), sf2[b], nb, jitter, True)
+            assert abs(lml[b] - O.log_marginal_likelihood(st)) < 1e-9 * abs(lml[b]) and lml_only[b] == lml[b]
+            assert relerr(grad[b], O.lml_gradient(st, ard=ard)) < 1e-7
+        # the fitted state was left alone by the trial evaluation
+        ok(lib.gpk_lml_batched(h, None, 0, _dp(lml), None))
+        assert relerr(lml, np.array([O.log_marginal_likelihood(s) for s in sts])) < 1e-10
+        ok(lib.gpk_model_release(h))
+        assert lib.gpk_predict_batched(h, _dp(X), 1, _dp(np.empty(B)), None, 1) == _lib.GPK_BAD_ARG
+        # bad arguments
+        assert lib.gpk_fit_batched(h, 9, _dp(X), N, D, _dp(Y), _dp(ls), n_ls, _dp(sf2), _dp(noise), jitter, 1, info) == _lib.GPK_BAD_ARG
+        assert lib.gpk_fit_batched(h, B, _dp(X), N, D, _dp(Y), _dp(ls), 2 if D != 2 else 3, _dp(sf2), _dp(noise), jitter, 1, info) == _lib.GPK_BAD_ARG
+    finally:
+        lib.gpk_destroy(h)
+
+
+def test_batched_composite_not_positive_definite():
+    """Duplicate training rows with zero noise and jitter: model 1's matrix is singular -> GPK_NOT_PD with the pivot in
+    info[1] while model 0 (with noise) factorises; in gpk_lml_batched the same trial point gives (-inf, 0) for that model
+    only (sklearn/_gpr.py:586-589)."""
+    from unmanned_aerial_vehicles_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    N, D, B = 300, 3, 2
+    X = rng.standard_normal((N, D))
+    X[150:] = X[:150]                                  # every row twice
+    Y = np.ascontiguousarray(rng.standard_normal((N, B)))
+    ls, sf2 = np.full((B, 1), 1.0), np.ones(B)
+    h = C.c_void_p()
+    assert lib.gpk_create(C.byref(h), 0) == _lib.GPK_OK
+    try:
+        assert lib.gpk_set_stream(h, C.c_void_p(-1)) == _lib.GPK_OK
+        info = (C.c_int * B)()
+        noise = np.array([0.1, 0.0])
+        assert lib.gpk_fit_batched(h, B, _dp(X), N, D, _dp(Y), _dp(ls), 1, _dp(sf2), _dp(noise), 0.0, 0, info) == _lib.GPK_NOT_PD
+        assert info[0] == 0 and 150 < info[1] <= 300
+        assert lib.gpk_predict_batched(h, _dp(X), 1, _dp(np.empty(B)), None, 1) == _lib.GPK_BAD_ARG
+        noise = np.array([0.1, 0.1])
+        assert lib.gpk_fit_batched(h, B, _dp(X), N, D, _dp(Y), _dp(ls), 1, _dp(sf2), _dp(noise), 0.0, 0, info) == _lib.GPK_OK
+        thetas = np.array([[0.0, np.log(0.1)], [0.0, -800.0]])        # exp(-800) = 0: singular for model 1
+        lml, grad = np.empty(B), np.ones((B, 2))
+        assert lib.gpk_lml_batched(h, _dp(thetas), 2, _dp(lml), _dp(grad)) == _lib.GPK_OK
+        st = O.fit_fixed(X, Y[:, 0], 1.0, 1.0, 0.1, 0.0, False)
+        assert abs(lml[0] - O.log_marginal_likelihood(st)) < 1e-9 * abs(lml[0]) and relerr(grad[0], O.lml_gradient(st)) < 1e-7
+        assert lml[1] == -np.inf and not grad[1].any()
+    finally:
+        lib.gpk_destroy(h)
+
+
+def test_batched_composite_against_sklearn_goldens(csv_data, ka):
+    """KA6 and KA6b (scikit-learn, per-output ARD model of gp_trainer.py:163-174 on the reference's flight CSV, two
+    hyper-parameter settings on the same target column) as the two models of one gpk_fit_batched call."""
+    from unmanned_aerial_vehicles_amd import _lib
+    lib = _lib.load()
+    X, Xq = np.ascontiguousarray(csv_data["X10"][:, :9]), np.ascontiguousarray(csv_data["Xq10"][:, :9])
+    y = csv_data["Y6"][:, 3]
+    N, D, B, M = X.shape[0], 9, 2, Xq.shape[0]
+    Y = np.ascontiguousarray(np.stack([y, y], axis=1))
+    ls = np.ascontiguousarray(np.stack([np.ones(9), ka["ka6b_ls"]]))
+    sf2, noise = np.ones(2), np.array([0.01, 0.05])
+    h = C.c_void_p()
+    assert lib.gpk_create(C.byref(h), 0) == _lib.GPK_OK
+    try:
+        assert lib.gpk_set_stream(h, C.c_void_p(-1)) == _lib.GPK_OK
+        info = (C.c_int * B)()
+        assert lib.gpk_fit_batched(h, B, _dp(X), N, D, _dp(Y), _dp(ls), D, _dp(sf2), _dp(noise), 1e-6, 0, info) == _lib.GPK_OK
+        lml = np.empty(B)
+        assert lib.gpk_lml_batched(h, None, 0, _dp(lml), None) == _lib.GPK_OK
+        assert relerr(lml, np.array([float(ka["ka6_lml"]), float(ka["ka6b_lml"])])) < 1e-10
+        mean, var = np.empty((M, B)), np.empty((M, B))
+        assert lib.gpk_predict_batched(h, _dp(Xq), M, _dp(mean), _dp(var), 1) == _lib.GPK_OK       # 64 rows: panel route
+        assert relerr(mean[:, 0], ka["ka6_mean"]) < 1e-8 and relerr(np.sqrt(var[:, 0]), ka["ka6_std"]) < 1e-8
+        assert relerr(mean[:, 1], ka["ka6b_mean"]) < 1e-8 and relerr(np.sqrt(var[:, 1]), ka["ka6b_std"]) < 1e-8
+        m25, v25 = np.empty((25, B)), np.empty((25, B))
+        assert lib.gpk_predict_batched(h, _dp(Xq), 25, _dp(m25), _dp(v25), 1) == _lib.GPK_OK       # one-call route
+        assert relerr(m25[:, 1], ka["ka6b_mean"][:25]) < 1e-8 and relerr(np.sqrt(v25[:, 0]), ka["ka6_std"][:25]) < 1e-8
+        thetas = np.ascontiguousarray(np.log(np.c_[ls, noise]))
+        grad = np.empty((B, D + 1))
+        assert lib.gpk_lml_batched(h, _dp(thetas), D + 1, _dp(lml), _dp(grad)) == _lib.GPK_OK
+        assert relerr(lml, np.array([float(ka["ka6_lml"]), float(ka["ka6b_lml"])])) < 1e-10
+        assert relerr(grad[0], ka["ka6_grad"]) < 1e-7 and relerr(grad[1], ka["ka6b_grad"]) < 1e-7
+    finally:
+        lib.gpk_destroy(h)

@@ -32,6 +32,9 @@ SIGNATURES = {
     "gpk_fit": (_int, [_vp, _dp, _i64, _int, _dp, _int, _dp, _int, _dbl, _dbl, _dbl, _int]),
     "gpk_predict": (_int, [_vp, _vp, _i64, _vp, _vp, _int, _int]),
     "gpk_lml": (_int, [_vp, _dp, _int, _dp, _dp]),
+    "gpk_fit_batched": (_int, [_vp, _int, _dp, _i64, _int, _dp, _dp, _int, _dp, _dp, _dbl, _int, C.POINTER(C.c_int)]),
+    "gpk_predict_batched": (_int, [_vp, _dp, _i64, _dp, _dp, _int]),
+    "gpk_lml_batched": (_int, [_vp, _dp, _int, _dp, _dp]),
     "gpk_export": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), _dp, _dp, _dp, _dp, _dp]),
     "gpk_import": (_int, [_vp, _dp, _i64, _int, _dp, _dp, _int, _dp, _int, _dbl, _dbl, _dp, _dp]),
     "gpk_model_release": (_int, [_vp]),

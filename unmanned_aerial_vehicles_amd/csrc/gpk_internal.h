@@ -11,10 +11,12 @@
 #include "../../include/gpk.h"
 
 struct gpk_model;    // the composite calls' model (gpk_model.hip)
+struct gpk_bmodel;   // B single-output models on shared inputs (gpk_fit_batched, gpk_model.hip)
 
 struct gpk_context {
   int device = 0;
   gpk_model* model = nullptr;        // owned: gpk_fit / gpk_import create it, gpk_destroy / gpk_model_release free it
+  gpk_bmodel* bmodel = nullptr;      // owned: gpk_fit_batched creates it, gpk_destroy / gpk_model_release free it
   hipStream_t stream = nullptr;      // stream kernels are launched on
   hipStream_t own_stream = nullptr;  // created by gpk_create
   bool user_stream = false;

@@ -144,8 +144,11 @@ constexpr int64_t EAGER_W_NP = 32768;
 
 }  // namespace
 
+void gpk_bmodel_free(gpk_handle h);
+
 void gpk_model_free(gpk_handle h) {
   if (h->model) { free_all(h->model); delete h->model; h->model = nullptr; }
+  gpk_bmodel_free(h);
 }
 
 extern "C" int gpk_model_release(gpk_handle h) {
@@ -417,5 +420,269 @@ extern "C" int gpk_import(gpk_handle h, const double* X, int64_t N, int D, const
   m->lml = std::numeric_limits<double>::quiet_NaN();
   m->normalize_y = -1;               // unknown: marks an imported model (gpk_lml(theta) needs the training targets)
   m->fitted = true;
+  return GPK_OK;
+}
+
+// ---- B single-output models on shared inputs (the per-axis GPs of src/px4/gp_trainer.py:139-179) ---------------------
+// gpk_fit_batched / gpk_predict_batched / gpk_lml_batched: the B factorisations, inverse factors and alpha solves run
+// as ONE launch chain (gpk_batch_begin: every kernel of the chain gets a batch grid dimension); the Gram build, the
+// LML reductions and the gradient reduction run once per model (their hyper-parameters differ).
+struct gpk_bmodel {
+  int B = 0, D = 0, n_ls = 0, normalize_y = 0;
+  int64_t N = 0, Ne = 0, Np = 0;
+  double jitter = 0.0;
+  double ls[GPK_MAX_BATCH][GPK_MAX_D_PREDICT] = {{0}};
+  double sf2[GPK_MAX_BATCH] = {0}, noise[GPK_MAX_BATCH] = {0}, y_mean[GPK_MAX_BATCH] = {0}, y_std[GPK_MAX_BATCH] = {0};
+  double lml[GPK_MAX_BATCH] = {0};
+  bool fitted = false;
+  double *X = nullptr, *Yn = nullptr, *alpha = nullptr, *alphaT = nullptr, *K = nullptr, *winv = nullptr, *W = nullptr;
+  double *sK = nullptr, *sW = nullptr, *sKinv = nullptr, *sT = nullptr, *swinv = nullptr, *salpha = nullptr;   // gpk_lml_batched
+  void *q = nullptr, *mean = nullptr, *work = nullptr;
+  double* var = nullptr;
+  size_t q_bytes = 0, mean_bytes = 0, work_bytes = 0, var_bytes = 0;
+  size_t nn() const { return (size_t)Np * Np; }
+  size_t tsz() const { return (size_t)(Np / 2 + 128) * (Np / 2 + 128); }
+};
+
+namespace {
+
+// alphaT[i][b] = alpha[b][i]: gpk_predict_mean_multi wants one column per model
+__global__ void rows_to_cols_kernel(const double* __restrict__ rows, long long N, long long Ne, int B, double* __restrict__ cols) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < N * B) cols[i] = rows[(i % B) * Ne + i / B];
+}
+
+// out[m][b] = var[m] * s2  (column b of the M x B variance block)
+__global__ void scale_var_col_kernel(const double* __restrict__ var, long long M, int B, int b, double s2, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < M) out[i * B + b] = var[i] * s2;
+}
+
+// K2 + W = L^-1 + K3 (+ K^-1 = W^T W) for all models in one launch chain; info[b] != 0: model b is not positive definite
+int batched_chain(gpk_handle h, gpk_bmodel* m, double* K, double* winv, double* W, double* T, double* alpha, double* Kinv,
+                  int* info) {
+  GPK_TRY(gpk_batch_begin(h, m->B));
+  int rc = GPK_OK;
+  const struct { const void* p; size_t stride; } bufs[] = {
+      {K, m->nn() * 8}, {winv, (size_t)m->Np * GPK_TILE * 8}, {W, m->nn() * 8}, {T, m->tsz() * 8},
+      {m->Yn, (size_t)m->Ne * 8}, {alpha, (size_t)m->Ne * 8}, {Kinv, m->nn() * 8}};
+  for (const auto& b : bufs)
+    if (rc == GPK_OK && b.p) rc = gpk_batch_buffer(h, b.p, (int64_t)b.stride);
+  if (rc == GPK_OK) {
+    rc = gpk_potrf(h, K, m->Np, m->Np, winv, info);
+    if (rc == GPK_NOT_PD) rc = GPK_OK;            // per-model outcome is in info[]
+  }
+  if (rc == GPK_OK) rc = gpk_trtri(h, K, m->Np, m->Np, winv, W, m->Np, T);
+  if (rc == GPK_OK) rc = gpk_potrs_inv(h, W, m->Np, m->Np, m->Yn, m->N, 1, alpha);
+  if (rc == GPK_OK && Kinv) rc = gpk_wtw(h, W, m->Np, m->Np, Kinv, m->Np);
+  (void)gpk_batch_end(h);
+  return rc;
+}
+
+void bfree_all(gpk_bmodel* m) {
+  void* ptrs[] = {m->X, m->Yn, m->alpha, m->alphaT, m->K, m->winv, m->W, m->sK, m->sW, m->sKinv, m->sT, m->swinv,
+                  m->salpha, m->q, m->mean, m->work, m->var};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+}
+
+}  // namespace
+
+void gpk_bmodel_free(gpk_handle h) {
+  if (h->bmodel) { bfree_all(h->bmodel); delete h->bmodel; h->bmodel = nullptr; }
+}
+
+extern "C" int gpk_fit_batched(gpk_handle h, int B, const double* X, int64_t N, int D, const double* Y, const double* ls,
+                               int n_ls, const double* sf2, const double* noise, double jitter, int normalize_y, int* info) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && Y && ls && sf2 && noise && info, "fit_batched: null pointer");
+  GPK_REQUIRE(h, B >= 1 && B <= GPK_MAX_BATCH, "fit_batched: 1..8 models");
+  GPK_REQUIRE(h, N >= 1 && D >= 1 && D <= GPK_MAX_D_PREDICT, "fit_batched: need N >= 1 and 1 <= D <= GPK_MAX_D_PREDICT");
+  GPK_REQUIRE(h, n_ls == 1 || n_ls == D, "fit_batched: n_ls must be 1 (isotropic) or D (ARD)");
+  GPK_REQUIRE(h, jitter >= 0.0, "fit_batched: jitter must be non-negative");
+  GPK_REQUIRE(h, h->batch == 1, "composite calls are not available in batched mode");
+  for (int b = 0; b < B; ++b) {
+    GPK_REQUIRE(h, sf2[b] > 0.0 && noise[b] >= 0.0, "fit_batched: sf2 must be positive, noise non-negative");
+    for (int d = 0; d < n_ls; ++d)
+      GPK_REQUIRE(h, ls[b * n_ls + d] > 0.0 && std::isfinite(ls[b * n_ls + d]), "fit_batched: length-scales must be positive");
+  }
+  for (int64_t i = 0; i < N * D; ++i) GPK_REQUIRE(h, std::isfinite(X[i]), "fit_batched: X contains NaN or infinity");
+  for (int64_t i = 0; i < N * B; ++i) GPK_REQUIRE(h, std::isfinite(Y[i]), "fit_batched: Y contains NaN or infinity");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  gpk_bmodel_free(h);
+  gpk_bmodel* m = new gpk_bmodel();
+  h->bmodel = m;
+  m->B = B; m->N = N; m->Ne = N + (N & 1); m->Np = gpk_padded(N); m->D = D; m->n_ls = n_ls; m->jitter = jitter;
+  m->normalize_y = normalize_y ? 1 : 0;
+  for (int b = 0; b < B; ++b) {
+    for (int d = 0; d < D; ++d) m->ls[b][d] = ls[b * n_ls + (n_ls == 1 ? 0 : d)];
+    m->sf2[b] = sf2[b]; m->noise[b] = noise[b];
+  }
+  // per-model rows (stride Ne: the batch strides must be multiples of 16 bytes, so odd N is padded by one entry)
+  std::vector<double> yn((size_t)B * m->Ne, 0.0);
+  for (int b = 0; b < B; ++b) {
+    double mean = 0.0, std_ = 1.0;
+    if (normalize_y) {          // population std; a (numerically) zero std counts as 1   (_gpr.py:271-282)
+      for (int64_t i = 0; i < N; ++i) mean += Y[i * B + b];
+      mean /= (double)N;
+      double v = 0.0;
+      for (int64_t i = 0; i < N; ++i) { const double d = Y[i * B + b] - mean; v += d * d; }
+      std_ = std::sqrt(v / (double)N);
+      if (std_ < 10.0 * std::numeric_limits<double>::epsilon()) std_ = 1.0;
+    }
+    m->y_mean[b] = mean; m->y_std[b] = std_;
+    for (int64_t i = 0; i < N; ++i) yn[(size_t)b * m->Ne + i] = (Y[i * B + b] - mean) / std_;
+  }
+  GPK_TRY(dev_alloc(h, &m->X, (size_t)N * D));
+  GPK_TRY(dev_alloc(h, &m->Yn, (size_t)B * m->Ne));
+  GPK_TRY(dev_alloc(h, &m->alpha, (size_t)B * m->Ne));
+  GPK_TRY(dev_alloc(h, &m->alphaT, (size_t)N * B));
+  GPK_TRY(dev_alloc(h, &m->K, (size_t)B * m->nn()));
+  GPK_TRY(dev_alloc(h, &m->winv, (size_t)B * m->Np * GPK_TILE));
+  GPK_TRY(dev_alloc(h, &m->W, (size_t)B * m->nn()));
+  double* T = nullptr;
+  GPK_TRY(dev_alloc(h, &T, (size_t)B * m->tsz()));
+  int rc = GPK_OK;
+  if (hipMemcpyAsync(m->X, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(m->Yn, yn.data(), yn.size() * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    rc = GPK_HIP_ERROR;
+  for (int b = 0; b < B && rc == GPK_OK; ++b)       // K1 per model
+    rc = gpk_gram(h, GPK_F64, m->X, N, D, m->ls[b], m->sf2[b], m->noise[b] + jitter, m->K + (size_t)b * m->nn(), m->Np);
+  if (rc == GPK_OK) rc = batched_chain(h, m, m->K, m->winv, m->W, T, m->alpha, nullptr, info);
+  if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
+  (void)hipFree(T);
+  GPK_TRY(rc);
+  bool all_pd = true;
+  for (int b = 0; b < B; ++b) {
+    if (info[b] != 0) { all_pd = false; m->lml[b] = -std::numeric_limits<double>::infinity(); continue; }
+    double terms[2];
+    GPK_TRY(gpk_lml_terms(h, m->K + (size_t)b * m->nn(), N, m->Np, m->Yn + (size_t)b * m->Ne, m->alpha + (size_t)b * m->Ne, 1, terms));
+    m->lml[b] = -0.5 * terms[1] - terms[0] - 0.5 * (double)N * std::log(2.0 * M_PI);
+  }
+  if (!all_pd) {
+    h->err = "fit_batched: a model's matrix is not positive definite (see info[])";
+    return GPK_NOT_PD;
+  }
+  const long long tot = (long long)N * B;
+  hipLaunchKernelGGL(rows_to_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, m->alpha, (long long)N,
+                     (long long)m->Ne, B, m->alphaT);
+  GPK_LAUNCH_CHECK(h);
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  m->fitted = true;
+  return GPK_OK;
+}
+
+extern "C" int gpk_predict_batched(gpk_handle h, const double* Xq, int64_t M, double* mean, double* var,
+                                   int var_includes_noise) {
+  if (!h) return GPK_BAD_ARG;
+  gpk_bmodel* m = h->bmodel;
+  GPK_REQUIRE(h, m && m->fitted, "predict_batched: no model (call gpk_fit_batched first)");
+  GPK_REQUIRE(h, Xq && mean && M >= 1, "predict_batched: null pointer or empty batch");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  const int B = m->B, D = m->D;
+  for (int64_t i = 0; i < M * D; ++i) GPK_REQUIRE(h, std::isfinite(Xq[i]), "predict_batched: Xq contains NaN or infinity");
+  double kss[GPK_MAX_BATCH];
+  for (int b = 0; b < B; ++b) kss[b] = m->sf2[b] + (var_includes_noise ? m->noise[b] : 0.0);
+  const double floor_ = var_includes_noise ? 0.0 : 1e-10;
+  double lsBD[GPK_MAX_BATCH * GPK_MAX_D_PREDICT];      // the length-scales as one contiguous (B x D) block
+  for (int b = 0; b < B; ++b)
+    for (int d = 0; d < D; ++d) lsBD[b * D + d] = m->ls[b][d];
+  // control-loop batches: one call, two launches for all models (src/px4/pretrained_gp.py:52-98)
+  if (M <= 32 && m->Np <= GPK_SMALL_MAX_NP) {
+    const double *Xs[GPK_MAX_BATCH], *as[GPK_MAX_BATCH], *Ws[GPK_MAX_BATCH];
+    for (int b = 0; b < B; ++b) { Xs[b] = m->X; as[b] = m->alpha + (size_t)b * m->Ne; Ws[b] = m->W + (size_t)b * m->nn(); }
+    std::vector<double> mb((size_t)B * M), vb(var ? (size_t)B * M : 0);
+    GPK_TRY(gpk_predict_host_multi(h, B, Xs, as, m->N, D, lsBD, m->sf2, m->y_mean, m->y_std, var ? Ws : nullptr, m->Np,
+                                   m->Np, var ? kss : nullptr, floor_, Xq, M, mb.data(), var ? vb.data() : nullptr));
+    for (int64_t i = 0; i < M; ++i)
+      for (int b = 0; b < B; ++b) {
+        mean[i * B + b] = mb[(size_t)b * M + i];
+        if (var) var[i * B + b] = vb[(size_t)b * M + i] * m->y_std[b] * m->y_std[b];
+      }
+    return GPK_OK;
+  }
+  int64_t panel = (int64_t)((4ull << 30) / ((size_t)m->Np * 8)) / GPK_TILE * GPK_TILE;
+  if (panel > 16384) panel = 16384;
+  if (panel < GPK_TILE) panel = GPK_TILE;
+  if (panel > gpk_padded(M)) panel = gpk_padded(M);
+  GPK_TRY(grow(h, &m->q, &m->q_bytes, (size_t)panel * D * 8));
+  GPK_TRY(grow(h, &m->mean, &m->mean_bytes, (size_t)panel * B * 8));
+  if (var) {
+    GPK_TRY(grow(h, &m->work, &m->work_bytes, (size_t)m->Np * panel * 8));
+    GPK_TRY(grow(h, (void**)&m->var, &m->var_bytes, (size_t)panel * 8 + (size_t)panel * B * 8));
+  }
+  double* d_varout = var ? m->var + panel : nullptr;
+  for (int64_t m0 = 0; m0 < M; m0 += panel) {
+    const int64_t mc = M - m0 < panel ? M - m0 : panel;
+    GPK_CHECK_HIP(h, hipMemcpyAsync(m->q, Xq + (size_t)m0 * D, (size_t)mc * D * 8, hipMemcpyHostToDevice, h->stream));
+    GPK_TRY(gpk_predict_mean_multi(h, GPK_F64, m->X, m->alphaT, m->N, D, B, lsBD, m->sf2, m->y_mean, m->y_std, m->q, mc, m->mean));
+    GPK_CHECK_HIP(h, hipMemcpyAsync(mean + (size_t)m0 * B, m->mean, (size_t)mc * B * 8, hipMemcpyDeviceToHost, h->stream));
+    if (var) {
+      for (int b = 0; b < B; ++b) {          // K* differs per model (its own length-scales): one variance launch each
+        GPK_TRY(gpk_predict_var_inv(h, GPK_F64, m->X, m->N, D, m->ls[b], m->sf2[b], m->W + (size_t)b * m->nn(), m->Np, m->Np,
+                                    m->q, mc, kss[b], floor_, m->work, m->var));
+        hipLaunchKernelGGL(scale_var_col_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, h->stream, m->var,
+                           (long long)mc, B, b, m->y_std[b] * m->y_std[b], d_varout);
+        GPK_LAUNCH_CHECK(h);
+      }
+      GPK_CHECK_HIP(h, hipMemcpyAsync(var + (size_t)m0 * B, d_varout, (size_t)mc * B * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  return GPK_OK;
+}
+
+extern "C" int gpk_lml_batched(gpk_handle h, const double* thetas, int n_theta, double* lml, double* grad) {
+  if (!h) return GPK_BAD_ARG;
+  gpk_bmodel* m = h->bmodel;
+  GPK_REQUIRE(h, m && m->fitted, "lml_batched: no model (call gpk_fit_batched first)");
+  GPK_REQUIRE(h, lml, "lml_batched: null pointer");
+  const int B = m->B, D = m->D;
+  if (!thetas) {
+    GPK_REQUIRE(h, !grad, "lml_batched: the gradient needs thetas");
+    for (int b = 0; b < B; ++b) lml[b] = m->lml[b];
+    return GPK_OK;
+  }
+  GPK_REQUIRE(h, n_theta == 2 || n_theta == D + 1, "lml_batched: each theta row holds log length-scale(s) and log noise");
+  GPK_CHECK_HIP(h, hipSetDevice(h->device));
+  const int nl = n_theta - 1;
+  double ls[GPK_MAX_BATCH][GPK_MAX_D_PREDICT], noise[GPK_MAX_BATCH];
+  for (int b = 0; b < B; ++b) {
+    for (int d = 0; d < D; ++d) ls[b][d] = std::exp(thetas[b * n_theta + (nl == 1 ? 0 : d)]);
+    noise[b] = std::exp(thetas[b * n_theta + nl]);
+  }
+  if (!m->sK) {
+    GPK_TRY(dev_alloc(h, &m->sK, (size_t)B * m->nn()));
+    GPK_TRY(dev_alloc(h, &m->sW, (size_t)B * m->nn()));
+    GPK_TRY(dev_alloc(h, &m->sT, (size_t)B * m->tsz()));
+    GPK_TRY(dev_alloc(h, &m->swinv, (size_t)B * m->Np * GPK_TILE));
+    GPK_TRY(dev_alloc(h, &m->salpha, (size_t)B * m->Ne));
+  }
+  if (grad && !m->sKinv) GPK_TRY(dev_alloc(h, &m->sKinv, (size_t)B * m->nn()));
+  for (int b = 0; b < B; ++b)
+    GPK_TRY(gpk_gram(h, GPK_F64, m->X, m->N, D, ls[b], m->sf2[b], noise[b] + m->jitter, m->sK + (size_t)b * m->nn(), m->Np));
+  int info[GPK_MAX_BATCH] = {0};
+  GPK_TRY(batched_chain(h, m, m->sK, m->swinv, m->sW, m->sT, m->salpha, grad ? m->sKinv : nullptr, info));
+  for (int b = 0; b < B; ++b) {
+    if (info[b] != 0) {              // inside an optimiser: LML = -inf, zero gradient (_gpr.py:586-589)
+      lml[b] = -std::numeric_limits<double>::infinity();
+      if (grad) for (int i = 0; i < n_theta; ++i) grad[b * n_theta + i] = 0.0;
+      continue;
+    }
+    double terms[2];
+    GPK_TRY(gpk_lml_terms(h, m->sK + (size_t)b * m->nn(), m->N, m->Np, m->Yn + (size_t)b * m->Ne, m->salpha + (size_t)b * m->Ne, 1, terms));
+    lml[b] = -0.5 * terms[1] - terms[0] - 0.5 * (double)m->N * std::log(2.0 * M_PI);
+    if (grad) {
+      double g[GPK_MAX_D_PREDICT + 2];
+      GPK_TRY(gpk_lml_grad(h, m->X, m->N, D, ls[b], m->sf2[b], noise[b], m->salpha + (size_t)b * m->Ne, 1,
+                           m->sKinv + (size_t)b * m->nn(), m->Np, g));
+      double* gb = grad + (size_t)b * n_theta;
+      if (nl == 1) { double s = 0.0; for (int d = 0; d < D; ++d) s += g[d]; gb[0] = s; }   // kernels.py:1574-1576
+      else for (int d = 0; d < D; ++d) gb[d] = g[d];
+      gb[nl] = g[D];
+    }
+  }
   return GPK_OK;
 }
