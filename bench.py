@@ -494,7 +494,7 @@ def main():
         elif method == "inverse_split2":
             key, peak = "k5_split2_kernel", MFMA_BF16_PEAK_TF        # fp16 MFMA: the same rate as bf16
             executed = 3.0 * flops
-            kernel = ("k5_split_kernel<4,2> (V = W K*^T, fp32 operands as 2 round-to-nearest fp16 parts, 3 x "
+            kernel = ("k5_split_kernel<4,2,4> (512 x 128 tiles; V = W K*^T, fp32 operands as 2 round-to-nearest fp16 parts, 3 x "
                       "v_mfma_f32_32x32x16_f16 per 32x32x16 block product, fp32 accumulation, fused column-norm epilogue, "
                       "1 launch/step)")
         else:

@@ -68,7 +68,8 @@ int64_t gpk_padded(int64_t n);
 /* gpk_set_option: the tuning knobs a fresh handle reads from the environment (GPK_K5_SPLIT_FORM, GPK_K5_SUPER,
  * GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle: "k5_split_form" (1: 32x32x16
  * MFMAs with register staging, 2: 16x16x32 fused-term MFMAs with LDS filled by DMA - two forms of the one launch behind
- * gpk_predict_var_inv_split, identical products), "k5_super", "small_path", "trsm256", "trtri_levels",
+ * gpk_predict_var_inv_split, identical products), "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = 512 x 128 tiles when
+ * at least 512 of them, 1 = always the 64 x 64-per-wave tiles, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256", "trtri_levels",
  * "gemm_small_tiles".  Used by the A/B timings and by the tests that pin a fast path to its plain form.            */
 int gpk_set_option(gpk_handle h, const char* name, int value);
 enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2 };

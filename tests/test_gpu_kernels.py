@@ -431,7 +431,7 @@ def test_split3_is_exact(be):
 
 
 @pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000)])
+@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300)])
 def test_variance_bf16_split_path(be, N, M, form):
     """K5 with the exact bf16x3 operand split (six bf16 MFMAs per fp32 block product) against the fp64 path and
     the fp32-MFMA path on the same queries: the same fp32 accuracy class (std within 1e-3 of fp64 - the stated
@@ -460,6 +460,15 @@ def test_variance_bf16_split_path(be, N, M, form):
         vs2 = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
         es2 = np.max(np.abs(np.sqrt(vs2) - np.sqrt(v64)) / np.sqrt(v64))
         assert es2 < 1e-3 and es2 < 2.0 * e32 + 1e-6, (e32, es2)
+        # its two tile configurations (64 x 64 per wave / 128 x 64 per wave in 512 x 128 tiles - the large-problem
+        # default, forced here; padded sizes that are not multiples of 512 keep the first): the same products, only the
+        # order of the epilogue's fp32 column sums differs
+        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 2))
+        vs2b = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
+        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 1))
+        vs2c = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
+        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 0))
+        assert np.array_equal(vs2c, vs2) and np.max(np.abs(vs2b - vs2)) <= 4e-6 * np.max(np.abs(vs2))
         w2, sc = dev.split2_inverse_factor()
         assert sc == 2.0 ** round(np.log2(sc)) and 16384.0 < sc * float(np.abs(np.tril(dev.inverse_factor(True).cpu().numpy())).max()) <= 32768.0
     with pytest.raises(ValueError):

@@ -55,16 +55,23 @@ if os.environ.get("SPLIT2", "1") == "1":
     else:
         dev.split2_inverse_factor()
         dev._Winv.pop("split", None)
-    dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
-    dev.timing(True)
-    for _ in range(reps):
-        v2 = dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
-    ms = dev.kernel_times(_lib.GPK_TIMED_K5)
-    dev.timing(False)
-    err = float(((v2.sqrt() - v64.sqrt()).abs() / v64.sqrt()).max())
-    print(f"fp16x2 split: kernel {np.mean(ms):8.2f} ms (min {np.min(ms):.2f} max {np.max(ms):.2f}) = "
-          f"{3.0 * N * N * M / np.mean(ms) / 1e9:7.1f} TF fp16, {M / np.mean(ms):6.1f} k pred/s kernel-only; "
-          f"std err vs fp64 {err:.2e}; scale {dev._Winv['split2'][1]:g}", flush=True)
+    # SPLIT2_TILES: tile variants of the fp16 x 2 launch (option k5_split2_tile - 1: 64 x 64 per wave in 256 x 128 tiles;
+    # 2: 128 x 64 per wave in 512 x 128 tiles; 0: the library's own rule)
+    ref2 = None
+    for form in [int(f) for f in os.environ.get("SPLIT2_TILES", "0").split(",")]:
+        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", form))
+        dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
+        dev.timing(True)
+        for _ in range(reps):
+            v2 = dev.predict_var_dev(q, 1.1, 0.0, "float32", "inverse_split2")
+        ms = dev.kernel_times(_lib.GPK_TIMED_K5)
+        dev.timing(False)
+        err = float(((v2.sqrt() - v64.sqrt()).abs() / v64.sqrt()).max())
+        ref2 = v2.clone() if ref2 is None else ref2
+        print(f"fp16x2 split (tile option {form}): kernel {np.mean(ms):8.2f} ms (min {np.min(ms):.2f} max {np.max(ms):.2f}) = "
+              f"{3.0 * N * N * M / np.mean(ms) / 1e9:7.1f} TF fp16, {M / np.mean(ms):6.1f} k pred/s kernel-only; "
+              f"std err vs fp64 {err:.2e}; max |v - v(first form)| {float((v2 - ref2).abs().max()):.2e}; scale {dev._Winv['split2'][1]:g}", flush=True)
+    be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 0))
 if 1 in res and 2 in res:
     print("max |form1 - form2| =", float((res[1][0] - res[2][0]).abs().max()), " repeatable:",
           all(torch.equal(a, res[f][0]) for f in res for a in res[f]))

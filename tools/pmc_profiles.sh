@@ -35,7 +35,7 @@ with open(out + "/pmc_hbm_traffic.md", "w") as fo:
         f_, w_ = res["FETCH_SIZE"][0][k], res["WRITE_SIZE"][0].get(k, 0.0)
         fo.write(f"| `{k[:110]}` | {res['FETCH_SIZE'][1][k]} | {f_:.0f} | {w_:.0f} | {(2 * f_ + w_) * 1024:.3e} |\n")
 entries = []
-for key, pat in (("k5_split2_kernel", "k5_split_kernel<4, 2>"), ("k5_split_kernel", "k5_split_kernel<4, 3>"),
+for key, pat in (("k5_split2_kernel", "k5_split_kernel<4, 2, 4>"), ("k5_split_kernel", "k5_split_kernel<4, 3, 2>"),
                  ("k5_split16_kernel", "k5_split16_kernel")):
     ks = [k for k in res["FETCH_SIZE"][0] if pat in k]
     if ks:
@@ -49,6 +49,7 @@ json.dump({"entries": entries}, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/pmc_hbm_traffic.md").read())
 PY
 rm -rf $out/prof $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+[ "$ONLY_TRAFFIC" = "1" ] && exit 0      # steps 1 and 2 only
 sets=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES" \
       "TCC_HIT_sum TCC_MISS_sum")
@@ -85,9 +86,9 @@ run_sets() {  # run_sets <dir> <program args...>
 }
 # split K5 (form 1 and form 2) at the headline shape
 FORMS=1,2 REPS=2 run_sets $out/k5forms python3 tools/exp_k5_forms.py
-summ $out/k5forms "k5_split_kernel<4, 3>" $out/pmc_mfma_k5_split_form1.txt
+summ $out/k5forms "k5_split_kernel<4, 3, 2>" $out/pmc_mfma_k5_split_form1.txt
 summ $out/k5forms "k5_split16_kernel" $out/pmc_mfma_k5_split_form2.txt
-summ $out/k5forms "k5_split_kernel<4, 2>" $out/pmc_mfma_k5_fp16x2.txt
+summ $out/k5forms "k5_split_kernel<4, 2, 4>" $out/pmc_mfma_k5_fp16x2.txt
 rm -rf $out/k5forms/p[0-9]
 # fp32-MFMA K5 and the fp64 GEMMs of potrf / trtri: one bench run with --var-method inverse
 run_sets $out/f32 python3 bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 0 --var-method inverse

@@ -6,12 +6,12 @@ i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  FORMS=1 REPS=2 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 tools/exp_k5_forms.py > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $out/p$i.log; }
+  FORMS=1 SPLIT2_TILES=0,1 REPS=2 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 tools/exp_k5_forms.py > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $out/p$i.log; }
 done
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]
-for pat, name in (("k5_split_kernel<4, 2>", "fp16x2"), ("k5_split_kernel<4, 3>", "bf16x3")):
+for pat, name in (("k5_split_kernel<4, 2, 4>", "fp16x2_512x128"), ("k5_split_kernel<4, 2, 2>", "fp16x2_256x128"), ("k5_split_kernel<4, 3, 2>", "bf16x3")):
     acc = collections.OrderedDict(); dur = []
     for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):

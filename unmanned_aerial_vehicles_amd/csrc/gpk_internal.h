@@ -43,6 +43,8 @@ struct gpk_context {
   int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
   int k5_split_form = 1;     // bf16 x 3 variance launch: 1 = 32x32x16 MFMAs, register-staged; 2 = 16x16x32 fused-term MFMAs,
                              // LDS filled by DMA (GPK_K5_SPLIT_FORM)
+  int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = 512 x 128 tiles (128 x 64 per wave) when >= 512 of them, else
+                             // 64 x 64 per wave; 1 = always 64 x 64 per wave; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // gpk_timing: HIP-event brackets around the dominant launches (K5 variance GEMM, K1 Gram kernel), a ring of pairs

@@ -33,7 +33,19 @@ template <int V> struct IntC { static constexpr int value = V; };
 constexpr int ROWB = 384;      // bytes of one k-tile (16 k) of a quad of rows: 4 rows x 2 halves x 3 parts x 16 B
 // the same two constants for NPART parts per value (3: bf16 x 3, exact; 2: fp16 x 2, 22 significant bits)
 template <int NPART> constexpr int rowb_v = 4 * 2 * NPART * 16;
-template <int NPART> constexpr int lrow_v = 2 * NPART * 16 + 16;      // 112 / 80 bytes = 4 x odd dwords: conflict-free b128 reads
+// LDS row of a k-tile: the row's 2 NPART chunks of 16 bytes plus 16 bytes of padding (112 / 80 bytes = 4 x odd dwords:
+// conflict-free ds_read_b128).  The padded 80-byte row of the fp16 x 2 split makes every ds_write_b128 2-way (banks
+// (a/4) % 32, 8 contiguous lanes = rows r and r+1, which overlap in 4 of the 32 store banks: SQ_LDS_BANK_CONFLICT = 31 % of
+// SQ_LDS_IDX_ACTIVE).  The swizzled form (SW = 2) has neither: 64-byte rows, no padding, chunk c of row r stored at
+// position c ^ ((r >> 2) & 3) - a ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: four row quads
+// whose (r >> 2) & 3 all differ) lands on 16 different 16-byte slots of the 256-byte bank row, and 8 contiguous lanes of a
+// store cover 128 contiguous bytes.  Measured on one box (profiles/r02_k5_forms_ab.log): zero conflicts and 2.4 % fewer
+// clock cycles, but the chip then holds 1.49 instead of 1.60 GHz under the 256 x 128-tile kernel (+5 % time); under the
+// 512 x 128-tile kernel it is 0.8 % faster.  So the swizzle is used with the large tile only.
+template <int SW, int NPART> constexpr int lrow_v = SW == 2 ? 64 : 2 * NPART * 16 + 16;
+template <bool SWZ> __device__ __forceinline__ int lds_chunk(int row, int chunk) {
+  return SWZ ? (chunk ^ ((row >> 2) & 3)) : chunk;
+}
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // bf16 part of a finite fp32 value, rounded to nearest even (as bits in the upper half of a dword)
@@ -137,19 +149,28 @@ __device__ __forceinline__ void load3(const char* __restrict__ ubase, const unsi
 // WR wave rows x 2 wave columns of 64 x 64 per workgroup: WR = 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU;
 // WR = 4 -> 256 x 128 tile, 8 waves, 1 workgroup per CU (25 % less operand staging per MFMA)
 // NPART = 3: bf16 parts, six products per block (exact); NPART = 2: fp16 parts, three products (a1 b0, a0 b1, a0 b0)
-template <int WR, int NPART = 3>
-__global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
-  constexpr int LROW = lrow_v<NPART>, ROWB = rowb_v<NPART>, CPR = 2 * NPART;      // (shadow the bf16 x 3 constants)
-  constexpr int TMR = 64 * WR;                                     // tile rows
+// AB: 32-row blocks per wave.  2: 64 x 64 per wave.  4 (with WR = 4): 128 x 64 per wave, 512 x 128 tiles, one
+// workgroup per CU at 2 waves per SIMD (256 VGPRs) - 17 % fewer operand bytes from L2 per product and 0.5 instead of
+// 0.67 fragment reads per MFMA: the launch is limited by the clock the chip holds under this load, and less data
+// movement per product is what raises it (9 % faster at the headline shape).  Needs >= 512 tiles to fill the chip.
+template <int WR, int NPART = 3, int AB = 2>
+__global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SParams p) {
+  constexpr bool SWZ = AB == 4;                                   // swizzled 64-byte LDS rows (see lrow_v)
+  constexpr int LROW = lrow_v<SWZ ? 2 : 3, NPART>, ROWB = rowb_v<NPART>, CPR = 2 * NPART;      // (shadow the bf16 x 3 constants)
+  constexpr int TMR = 32 * AB * WR;                                // tile rows
   constexpr int SSZ = (TMR + 128) * LROW;                          // one LDS stage: [A k-tile | B k-tile]
   constexpr int BOFF = TMR * LROW;                                 // B inside a stage
+  // byte offsets of the A / B k-tile of LDS buffer `buf`.  AB = 4: [B0 | B1 | A0 | A1], so that every fragment read is
+  // within 64 KiB (the ds offset field) of one base register per operand and swizzle variant; else [A0 | B0 | A1 | B1].
+  auto AO = [](int buf) constexpr { return AB == 4 ? 2 * 128 * LROW + buf * TMR * LROW : buf * SSZ; };
+  auto BO = [](int buf) constexpr { return AB == 4 ? buf * 128 * LROW : buf * SSZ + BOFF; };
   __shared__ __attribute__((aligned(16))) char lds[2 * SSZ];
-  constexpr int NT = WR * 128, AB = 2, NCH = (TMR + 128) * CPR, NQ = (NCH + NT - 1) / NT;   // threads, blocks, chunks
+  constexpr int NT = WR * 128, NCH = (TMR + 128) * CPR, NQ = (NCH + NT - 1) / NT;   // threads, chunks
   constexpr int GSZ = WR == 2 ? 64 : 32;                           // resident workgroups per XCD = tiles per group
   constexpr int BH = 1024 / TMR;                                   // band height in tile rows (1024 matrix rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int row_w = wm * 64, col_w = wn * 64;
+  const int row_w = wm * 32 * AB, col_w = wn * 64;
 
   // ---- tile mapping: bands of 1024 rows walked column by column in groups of GSZ tiles, serpentine over XCDs
   const int ntm = p.ntm * 128 / TMR;                               // tile rows of this configuration
@@ -198,8 +219,15 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
     isb[q] = __builtin_amdgcn_readfirstlane(g >= TMR * CPR ? 1 : 0) != 0;
     const int c = live[q] ? (isb[q] ? g - TMR * CPR : g) : 0, row = c / CPR, w = c - row * CPR;
     goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * CPR + w) * 16);     // rsa: bytes between row quads
-    lofs[q] = (isb[q] ? BOFF : 0) + row * LROW + w * 16;
+    lofs[q] = (isb[q] ? BOFF : 0) + row * LROW + lds_chunk<SWZ>(row, w) * 16;
   }
+  // fp16 x 2 (four chunks per row, NT a multiple of four, the A / B boundary on a multiple of NT): chunk q of a thread is
+  // its chunk 0 moved down NT / 4 rows per q - one vector offset plus a scalar step per q for the global address, one
+  // LDS offset plus constants for the store (NQ - 1 fewer address registers of each kind)
+  constexpr bool AFF = NPART == 2;
+  constexpr int QA = TMR * CPR / NT, QROWS = NT / CPR;
+  static_assert(!AFF || ((TMR * CPR) % NT == 0 && NCH % NT == 0 && NT % CPR == 0), "affine chunk addressing");
+  const int gstep = (int)((QROWS / 4) * p.rsa);                     // bytes between a thread's consecutive chunks (rsa == rsb)
   const char* ua = p.A + (long long)(row0 >> 2) * p.rsa;
   const char* ub = p.B + (long long)(col0 >> 2) * p.rsb;
   // Register ring of RING k-tiles in flight: the fetch of k-tile kt+1+RING is issued when k-tile kt+1 leaves its
@@ -215,6 +243,15 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   auto fetch = [&](int tile, auto slotc) {
     constexpr int sl = decltype(slotc)::value;
     const long long ko = (long long)min(tile, nkt - 1) * ROWB;
+    if constexpr (AFF) {
+      const __amdgpu_buffer_rsrc_t rsa_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ua + ko), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ub + ko), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        rr[sl][q] = q < QA ? __builtin_amdgcn_raw_buffer_load_b128(rsa_, goff[0], q * gstep, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rsb_, goff[0], (q - QA) * gstep, 0);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       if (NCH % NT != 0 && !live[q]) continue;      // (only the last chunk of the 256-row configuration can be absent)
@@ -223,8 +260,16 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
       rr[sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[q], 0, 0);
     }
   };
-  auto stage = [&](char* buf, auto slotc) {
-    constexpr int sl = decltype(slotc)::value;
+  auto stage = [&](auto bufc, auto slotc) {
+    constexpr int sl = decltype(slotc)::value, bi = decltype(bufc)::value;
+    if constexpr (AFF) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        *reinterpret_cast<V16*>(lds + lofs[0] + (q < QA ? AO(bi) + q * QROWS * LROW : BO(bi) + (q - QA) * QROWS * LROW)) = rr[sl][q];
+      return;
+    }
+    static_assert(AFF || AB != 4, "the [B | A] buffer order is used with affine chunk addressing only");
+    char* buf = lds + bi * SSZ;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (NCH % NT == 0 || live[q]) *reinterpret_cast<V16*>(buf + lofs[q]) = rr[sl][q];
@@ -257,17 +302,18 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
         acc[a][b] = c;
       }
   };
-  auto frags = [&](const char* buf, bf16x8 (&af)[AB][NPART], bf16x8 (&bf)[2][NPART]) {
+  auto frags = [&](auto bufc, bf16x8 (&af)[AB][NPART], bf16x8 (&bf)[2][NPART]) {
+    constexpr int bi = decltype(bufc)::value;
 #pragma unroll
     for (int a = 0; a < AB; ++a)
 #pragma unroll
       for (int s = 0; s < NPART; ++s)
-        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + (row_w + 32 * a + fr) * LROW + (fh * NPART + s) * 16));
+        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + AO(bi) + (row_w + 32 * a + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + s) * 16));
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int s = 0; s < NPART; ++s)
-        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(buf + BOFF + (col_w + 32 * b + fr) * LROW + (fh * NPART + s) * 16));
+        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + BO(bi) + (col_w + 32 * b + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + s) * 16));
   };
 #if GPK_K5S_FPRE
   // Fragments one k-tile ahead: while the MFMAs of k-tile kt run out of registers F[kt & 1], the fragments of k-tile
@@ -275,22 +321,92 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   // (its previous content, k-tile kt, was read during iteration kt-1; the barrier at the end of each iteration
   // separates the two).  No MFMA waits for LDS.
   static_assert(RING == 2, "the fragment-prefetch pipeline is written for a ring of two k-tiles");
-  bf16x8 FA[2][AB][NPART], FB[2][2][NPART];
+  // (AB = 4: the A fragments are single-buffered - a row block's fragments of the next k-tile replace the ones its
+  // MFMAs have just used - which keeps the 128 x 64 wave tile inside 256 registers)
+  constexpr int NFA = AB == 4 ? 1 : 2;
+  bf16x8 FA[NFA][AB][NPART], FB[2][2][NPART];
   fetch(0, IntC<0>{});
-  stage(lds, IntC<0>{});
+  stage(IntC<0>{}, IntC<0>{});
   fetch(1, IntC<1>{});
-  stage(lds + SSZ, IntC<1>{});
+  stage(IntC<1>{}, IntC<1>{});
   fetch(2, IntC<0>{});
   fetch(3, IntC<1>{});
   __syncthreads();
-  frags(lds, FA[0], FB[0]);
+  frags(IntC<0>{}, FA[0], FB[0]);
   __syncthreads();
+  // (AB = 4: the last row block's A fragments ARE double-buffered, so that an iteration can end with that block's MFMAs
+  // and its LDS reads are long complete at the barrier)
+  bf16x8 FA3[2][NPART];
+  if constexpr (AB == 4) {
+#pragma unroll
+    for (int sp = 0; sp < NPART; ++sp) FA3[0][sp] = FA[0][AB - 1][sp];
+  }
   auto body = [&](int kt, auto ksc) {
     constexpr int KS = decltype(ksc)::value, cur = KS & 1;
-    stage(lds + cur * SSZ, IntC<cur>{});            // k-tile kt+2 (ring slot (kt+2) % 2 = cur)
+    if constexpr (AB == 4) {
+      // The 128 x 64 wave tile, issue order written out and fenced (sched_barrier: nothing moves across): MFMAs from the
+      // first cycle after the barrier (their operands are in registers); k-tile kt+2 goes from the ring registers to LDS
+      // buffer `cur` one store per three MFMAs, each global load of k-tile kt+4 behind the store that frees its
+      // registers; a row block's A fragments of k-tile kt+1 are read behind that block's MFMAs, the B fragments and the
+      // last block's (double-buffered) A fragments before the last twelve MFMAs, which end the iteration.
+      static_assert(AB != 4 || (NPART == 2 && NQ == 5 && AFF), "the 128 x 64 wave tile is written for the fp16 x 2 split");
+      const long long ko = (long long)min(kt + 4, nkt - 1) * ROWB;
+      const __amdgpu_buffer_rsrc_t rsa_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ua + ko), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ub + ko), 0, 0x7fffffff, 0x00020000);
+      auto st = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        *reinterpret_cast<V16*>(lds + lofs[0] + (q < QA ? AO(cur) + q * QROWS * LROW : BO(cur) + (q - QA) * QROWS * LROW)) = rr[cur][q];
+      };
+      auto ld = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        rr[cur][q] = q < QA ? __builtin_amdgcn_raw_buffer_load_b128(rsa_, goff[0], q * gstep, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rsb_, goff[0], (q - QA) * gstep, 0);
+      };
+      auto rdA = [&](int a, bf16x8 (&dst)[NPART]) {
+#pragma unroll
+        for (int sp = 0; sp < NPART; ++sp)
+          dst[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + AO(cur ^ 1) + (row_w + 32 * a + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + sp) * 16));
+      };
+      auto rdB = [&](int b_, bf16x8 (&dst)[NPART]) {
+#pragma unroll
+        for (int sp = 0; sp < NPART; ++sp)
+          dst[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + BO(cur ^ 1) + (col_w + 32 * b_ + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + sp) * 16));
+      };
+      auto mm = [&](int a, int b, const bf16x8 (&fa)[NPART], const bf16x8 (&fb)[NPART]) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, fa[0]), a1 = __builtin_bit_cast(f16x8, fa[1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, fb[0]), b1 = __builtin_bit_cast(f16x8, fb[1]);
+        f16v c = acc[a][b];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);       // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+        acc[a][b] = c;
+      };
+      // column block 0 first (its B fragments are single-buffered: FB[0][0], reloaded once its four products are done),
+      // then column block 1 (FB[cur][1]; the row blocks' A fragments are reloaded behind their second product)
+#define GPK_FENCE() __builtin_amdgcn_sched_barrier(0)
+      mm(0, 0, FA[0][0], FB[0][0]); GPK_FENCE();
+      st(IntC<0>{}); GPK_FENCE();
+      mm(1, 0, FA[0][1], FB[0][0]); GPK_FENCE();
+      st(IntC<1>{}); GPK_FENCE();
+      mm(2, 0, FA[0][2], FB[0][0]); GPK_FENCE();
+      st(IntC<2>{}); GPK_FENCE();
+      mm(3, 0, FA3[cur], FB[0][0]); GPK_FENCE();
+      st(IntC<3>{}); rdB(0, FB[0][0]); GPK_FENCE();
+      mm(0, 1, FA[0][0], FB[cur][1]); GPK_FENCE();
+      st(IntC<4>{}); ld(IntC<0>{}); rdA(0, FA[0][0]); GPK_FENCE();
+      mm(1, 1, FA[0][1], FB[cur][1]); GPK_FENCE();
+      ld(IntC<1>{}); ld(IntC<2>{}); rdA(1, FA[0][1]); GPK_FENCE();
+      mm(2, 1, FA[0][2], FB[cur][1]); GPK_FENCE();
+      ld(IntC<3>{}); ld(IntC<4>{}); rdA(2, FA[0][2]); rdB(1, FB[cur ^ 1][1]); rdA(3, FA3[cur ^ 1]); GPK_FENCE();
+      mm(3, 1, FA3[cur], FB[cur][1]); GPK_FENCE();
+#undef GPK_FENCE
+      __syncthreads();
+      return;
+    }
+    stage(IntC<cur>{}, IntC<cur>{});            // k-tile kt+2 (ring slot (kt+2) % 2 = cur)
     fetch(kt + 4, IntC<cur>{});
-    frags(lds + (cur ^ 1) * SSZ, FA[cur ^ 1], FB[cur ^ 1]);
-    mfmas(FA[cur], FB[cur]);
+    frags(IntC<(cur ^ 1)>{}, FA[(cur ^ 1) % NFA], FB[cur ^ 1]);
+    mfmas(FA[cur % NFA], FB[cur]);
 #if GPK_K5S_SCHED
     constexpr int NMF = (NPART == 3 ? 6 : 3) * AB * 2, NRD = NPART * (AB + 2);
     __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
@@ -305,7 +421,7 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   };
 #else
   fetch(0, IntC<0>{});
-  stage(lds, IntC<0>{});
+  stage(IntC<0>{}, IntC<0>{});
   fetch(1, IntC<1 % RING>{});
   if constexpr (RING >= 2) fetch(2, IntC<2 % RING>{});
   if constexpr (RING >= 3) fetch(3, IntC<3 % RING>{});
@@ -315,10 +431,10 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   // slot is refilled with k-tile kt+1+RING, and k-tile kt is multiplied out of LDS buffer kt & 1
   auto body = [&](int kt, auto ksc) {
     constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
-    stage(lds + (cur ^ 1) * SSZ, IntC<sl>{});
+    stage(IntC<(cur ^ 1)>{}, IntC<sl>{});
     fetch(kt + 1 + RING, IntC<sl>{});
     bf16x8 af[AB][NPART], bf[2][NPART];
-    frags(lds + cur * SSZ, af, bf);
+    frags(IntC<cur>{}, af, bf);
     mfmas(af, bf);
 #if GPK_K5S_SCHED
     // issue order: LDS writes of the next k-tile, all twelve fragment reads, then the MFMAs with the six
@@ -626,8 +742,14 @@ extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t 
     GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
     GPK_TRY(gpk_split2(h, work, Mp, Np, Np, k_scale, work2));
   }
-  const int wr = (Np % 256 == 0) ? 4 : 2;
-  const int ntmT = (int)(Np / (64 * wr)), gsz = wr == 2 ? 64 : 32;
+  // 512 x 128 tiles (128 x 64 per wave) when they come in at least two rounds of the 256 CUs; 256 x 128 or 128 x 128
+  // tiles (64 x 64 per wave) otherwise.  Option "k5_split2_tile": 0 = this rule, 1 = always 64 x 64 per wave, 2 = 512 x 128
+  // whenever Np allows.
+  const bool big_ok = Np % 512 == 0 && Np * 1536 < (1ll << 31);
+  const bool big = big_ok && (h->k5_split2_tile == 2 || (h->k5_split2_tile == 0 && (Np / 512) * (long long)ntn >= 512));
+  const int ab = big ? 4 : 2;
+  const int wr = big ? 4 : ((Np % 256 == 0) ? 4 : 2);
+  const int ntmT = (int)(Np / (32 * ab * wr)), gsz = wr == 2 ? 64 : 32;
   void* partial = nullptr;
   GPK_TRY(gpk_scratch(h, (size_t)ntmT * Mp * sizeof(double), &partial));
   SParams p;
@@ -638,7 +760,8 @@ extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t 
   p.alpha = (float)(1.0 / (w_scale * k_scale));      // undo both operand scalings (powers of two: exact)
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
   gpk_time_begin(h, GPK_TIMED_K5);
-  if (wr == 4) hipLaunchKernelGGL((k5_split_kernel<4, 2>), dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  if (ab == 4) hipLaunchKernelGGL((k5_split_kernel<4, 2, 4>), dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  else if (wr == 4) hipLaunchKernelGGL((k5_split_kernel<4, 2>), dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
   else hipLaunchKernelGGL((k5_split_kernel<2, 2>), dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
   gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);
