@@ -515,6 +515,10 @@ def main():
                 "fp32_equivalent_TFLOPs": flops / k5_s / 1e12,
                 "traffic": tr["bytes_per_launch"] if tr else None,
                 "traffic_source": tr["source"] if tr else None,
+                # committed counter passes of this kernel at this shape (not collected in this process): how busy the matrix
+                # pipe is and the clock the chip holds under it - the product of the two is what `frac` can reach
+                "pmc": ({k: tr[k] for k in ("pmc_mfma_busy", "pmc_clock_ghz", "pmc_source", "zero_operand_frac_of_peak",
+                                            "zero_operand_source") if k in tr} or None) if tr else None,
                 "launches_per_step": 1 if method != "solve" else 2 * (dev.Np // 128) - 1,
                 "kernel_ms": k5_s * 1e3, "kernel_ms_min_max": [float(np.min(k5_ms)), float(np.max(k5_ms))] if len(k5_ms) else None,
                 "timed_launches": int(len(k5_ms)),
