@@ -431,12 +431,13 @@ def test_split3_is_exact(be):
 
 
 @pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300)])
+@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300), (8192, 4200)])
 def test_variance_bf16_split_path(be, N, M, form):
     """K5 with the exact bf16x3 operand split (six bf16 MFMAs per fp32 block product) against the fp64 path and
     the fp32-MFMA path on the same queries: the same fp32 accuracy class (std within 1e-3 of fp64 - the stated
     fp32 tolerance - and within 2x of the fp32-MFMA path's own error), in super-tile mode (N = 5000: 40 x 2 tiles
-    is direct; N = 3000 x 700: 24 x 6) and with ragged sizes.  Both forms of the launch (gpk_set_option
+    is direct; N = 3000 x 700: 24 x 6) and with ragged sizes (N = 8192 x 4200: 16 x 33 tiles of 512 x 128 - the library's own
+    rule picks the large-tile fp16 x 2 kernel there).  Both forms of the launch (gpk_set_option
     "k5_split_form": 32x32x16 MFMAs with register staging / 16x16x32 fused-term MFMAs with LDS filled by DMA; the second
     serves padded sizes that are multiples of 256 - N = 2500 pads to 2560 - and falls back to the first otherwise)."""
     from unmanned_aerial_vehicles_amd.device import DeviceGP
@@ -468,7 +469,8 @@ def test_variance_bf16_split_path(be, N, M, form):
         be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 1))
         vs2c = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
         be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 0))
-        assert np.array_equal(vs2c, vs2) and np.max(np.abs(vs2b - vs2)) <= 4e-6 * np.max(np.abs(vs2))
+        assert np.array_equal(vs2, vs2b if (dev.Np // 512) * (-(-M // 128)) >= 512 and dev.Np % 512 == 0 else vs2c)     # the rule
+        assert np.max(np.abs(vs2b - vs2c)) <= 4e-6 * np.max(np.abs(vs2c))
         w2, sc = dev.split2_inverse_factor()
         assert sc == 2.0 ** round(np.log2(sc)) and 16384.0 < sc * float(np.abs(np.tril(dev.inverse_factor(True).cpu().numpy())).max()) <= 32768.0
     with pytest.raises(ValueError):
