@@ -732,7 +732,8 @@ extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t 
   GPK_REQUIRE(h, w_scale > 0.0 && sf2 > 0.0, "predict_var_inv_split2: scales must be positive");
   const int64_t Mp = gpk_padded(M);
   const int ntm = (int)(Np / 128), ntn = (int)(Mp / 128);
-  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 4 * 128 < (1ll << 31), "predict_var_inv_split2: size too large");
+  // (buffer offsets are 32-bit: a tile's last row quad lies (TMR / 4) * 16 Np bytes beyond its first - at most 2048 Np)
+  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 2048 < (1ll << 31), "predict_var_inv_split2: size too large");
   // K* in (0, sf2]: the power of two that puts sf2 just below 2^15
   const double k_scale = std::ldexp(1.0, 14 - (int)std::floor(std::log2(sf2)));
   if (D <= 16 && Mp / 64 < 65536) {
@@ -745,7 +746,7 @@ extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t 
   // 512 x 128 tiles (128 x 64 per wave) when they come in at least two rounds of the 256 CUs; 256 x 128 or 128 x 128
   // tiles (64 x 64 per wave) otherwise.  Option "k5_split2_tile": 0 = this rule, 1 = always 64 x 64 per wave, 2 = 512 x 128
   // whenever Np allows.
-  const bool big_ok = Np % 512 == 0 && Np * 1536 < (1ll << 31);
+  const bool big_ok = Np % 512 == 0;
   const bool big = big_ok && (h->k5_split2_tile == 2 || (h->k5_split2_tile == 0 && (Np / 512) * (long long)ntn >= 512));
   const int ab = big ? 4 : 2;
   const int wr = big ? 4 : ((Np % 256 == 0) ? 4 : 2);
@@ -777,7 +778,7 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   GPK_REQUIRE(h, h->batch == 1, "predict_var_inv_split: not available in batched mode");
   const int64_t Mp = gpk_padded(M);
   const int ntm = (int)(Np / 128), ntn = (int)(Mp / 128);
-  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 6 * 128 < (1ll << 31), "predict_var_inv_split: size too large");
+  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 24 * 64 < (1ll << 31), "predict_var_inv_split: size too large");
   // Kq (Mp x Np, query-major, k contiguous) = k(Xq, X) in fp32, then its exact three-way bf16 split
   GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
   GPK_TRY(gpk_split3(h, work, Mp, Np, Np, work3));
