@@ -44,7 +44,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3      # dense fp32 MFMA (= fp32 vector peak)
 MFMA_F64_PEAK_TF = 78.6       # fp64 matrix peak (MI355X datasheet; used for the Cholesky fraction only)
 MFMA_BF16_PEAK_TF = 2516.6    # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz (guide: "~2.5 PF dense")
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.sh from --pmc passes
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from the --pmc passes of tools/pmc_k5.sh
 
 
 def parse_args(argv=None):
@@ -63,9 +63,10 @@ def parse_args(argv=None):
                          "row-sharded over the GPUs with no exchange (SURVEY 8e; strong scaling, GB/s)")
     ap.add_argument("--var-method", default="auto", choices=["auto", "inverse_split", "inverse_split2", "inverse", "solve"],
                     help="auto = inverse_split2: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch on the "
-                         "16-bit matrix pipe, every fp32 operand as two round-to-nearest fp16 parts (represented to 2^-24), "
-                         "three products per block, fp32 accumulation; inverse_split: three exact bf16 parts, six products; "
-                         "inverse: the same launch on the exact-fp32 MFMA; solve: blocked triangular solve chain")
+                         "16-bit matrix pipe, every fp32 operand as two round-to-nearest fp16 parts (represented to 2^-23), "
+                         "three products per block, fp32 accumulation, operands from L2 straight into registers; "
+                         "inverse_split: three exact bf16 parts, six products; inverse: the same launch on the exact-fp32 "
+                         "MFMA; solve: blocked triangular solve chain")
     return ap.parse_args(argv)
 
 
@@ -134,14 +135,15 @@ def cpu_baseline(M_sample=2000, N_sample=8192, n_full=65536):
         t_pred = time.perf_counter() - t0
         what = "oracle/gp_oracle.py (NumPy/SciPy restatement)"
     v = M_sample / t_pred
-    return {"value": v, "unit": "predictions/s", "cores": cores, "kind": kind,
-            "n_train_of_sample": N_sample,
-            # predict cost grows as N_train^2 (the triangular solve): the like-for-like figure at the headline size
-            "extrapolated_value_at_n_train": {"n_train": n_full, "value": v * (N_sample / float(n_full)) ** 2,
-                                              "rule": "value x (n_train_of_sample / n_train)^2"},
-            "sample": f"{what}: predict(return_std=True) of {M_sample} queries at N_train={N_sample} (not {n_full}: the "
-                      f"CPU fit alone would take ~10 min and 100 GB); fit {t_fit:.1f} s untimed, predict {t_pred:.2f} s",
-            "fit_seconds_at_sample": t_fit}
+    # `value` is the like-for-like figure at the headline N_train: predict cost grows as N_train^2 (the triangular solve), so
+    # the sample's rate is scaled by (n_train_of_sample / n_train)^2 - and replaced by a MEASURED rate when the host has the
+    # memory to run scikit-learn's predict on the full-size factor (main(): cpu_full_size_predict)
+    return {"value": v * (N_sample / float(n_full)) ** 2, "unit": "predictions/s", "cores": cores, "kind": kind,
+            "n_train": n_full, "basis": "extrapolated", "rule": "sample value x (n_train_of_sample / n_train)^2",
+            "sample_at_smaller_n_train": {"value": v, "n_train": N_sample, "queries": M_sample, "predict_seconds": t_pred,
+                                          "fit_seconds": t_fit},
+            "sample": f"{what}: predict(return_std=True) of {M_sample} queries at N_train={N_sample} (fit {t_fit:.1f} s untimed, "
+                      f"predict {t_pred:.2f} s), scaled to N_train={n_full}"}
 
 
 def cpu_full_size_predict(dev, X, y_mean, y_std, alpha_host, ls, noise, M_cpu=200):
@@ -266,6 +268,9 @@ def main():
     if (args.gpus > 1 or os.environ.get("BENCH_FORCE_LAUNCH") == "1") and "RANK" not in os.environ:
         launch_ranks(args)                     # does not return
 
+    # dmabuf IPC: required by RCCL on this host driver - set before torch / HIP come up, on BOTH launch routes (the
+    # driver's own torch.distributed.run never passes through launch_ranks)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -332,10 +337,10 @@ def main():
     dev.timing(True)
     dev.gram(ls, sf2, noise + jitter)            # warm-up of the Gram kernel + allocation
     torch.cuda.synchronize()
-    for _ in range(3):
+    for _ in range(6):
         dev.gram(ls, sf2, noise + jitter)
-    gram_times = dev.kernel_times(_lib.GPK_TIMED_GRAM)[-3:] * 1e-3     # HIP events around the Gram kernel launches
-    gram_s = float(sorted(gram_times)[1])                               # median of 3
+    gram_times = dev.kernel_times(_lib.GPK_TIMED_GRAM)[-6:] * 1e-3     # HIP events around the Gram kernel launches
+    gram_s = float(np.mean(gram_times))                                 # the average (what a rocprofv3 --stats row shows)
     gram_bytes = dev.Np * dev.Np * 8 + N * D * 8          # N^2 s + N D s (s = 8)
     info = C.c_int(0)
     t0 = time.perf_counter()
@@ -374,7 +379,8 @@ def main():
     dev._f32_data()
     torch.cuda.synchronize()
     fit = {"n_train": N, "dtype": "f64",
-           "gram_ms": gram_s * 1e3, "gram_GBps": gram_bytes / gram_s / 1e9,
+           "gram_ms": gram_s * 1e3, "gram_ms_min_avg_max": [float(gram_times.min() * 1e3), gram_s * 1e3, float(gram_times.max() * 1e3)],
+           "gram_launches_timed": int(len(gram_times)), "gram_GBps": gram_bytes / gram_s / 1e9,
            "gram_frac_of_hbm_peak": gram_bytes / gram_s / 1e9 / HBM_PEAK_GBPS,
            "cholesky_s": potrf_s, "cholesky_GFLOPs": N ** 3 / 3.0 / potrf_s / 1e9,
            "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
@@ -391,17 +397,18 @@ def main():
     # ---------------------------------------------------------------- the timed hot path
     kss = sf2 + noise
     ystd2 = torch.as_tensor(y_std ** 2, device=be.device, dtype=torch.float64)
+    assert c4 or dev.fp32_mean_ok(), "the benchmark model must pass the fp32 mean gate (it is served in fp32)"
 
     def step_c4():
         mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4 only
         return all_gather_rows(mean, M * world) if use_dist else mean
 
     def step_c3():
-        mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4
-        var = dev.predict_var_dev(q32, kss, 0.0, "float32", method)                 # K5
-        out = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1)      # (M, 2P)
+        # K4 + K* + K5 + finalise (un-normalise, pack [mean | var], count the rows the fp32 variance gate must recompute):
+        # libgpk launches only - the production serving path, gates included (DeviceGP.predict_packed_dev)
+        out = dev.predict_packed_dev(q32, y_mean, y_std, kss, 0.0, "float32", method)     # (M, 2P) float64
         if use_dist:
-            out = all_gather_rows(out, M * world)                                   # RCCL all-gather
+            out = all_gather_rows(out, M * world)                                           # RCCL all-gather
         return out
 
     step = step_c4 if c4 else step_c3
@@ -476,52 +483,62 @@ def main():
                 "algorithmic_TFLOPs_all_pipes": flops / k4_s / 1e12,
                 "traffic": None, "k4_ms": k4_s * 1e3, "algorithmic_flops_per_step": flops}
     if rank == 0 and not c4:
-        flops = float(N) * float(N) * float(M)      # N^2 flops per prediction (K5), fp32-equivalent
-        k5_s = float(np.mean(k5_ms)) * 1e-3 if len(k5_ms) else float("nan")
+        flops = float(N) * float(N) * float(M)      # N^2 M algorithmic (fp32-equivalent) flops per step (K5)
+        # per-STEP kernel time: the bracketed launches of one step summed (a batch larger than the variance panel is
+        # several launches; the ring keeps the last 64 launches, so only whole steps still in it are used)
+        lps = max(1, -(-M // max(128, min(dev.VAR_PANEL_MAX, (dev.VAR_PANEL_BYTES // (dev.Np * 4)) // 128 * 128))))
         if method == "solve":                       # the chain's launches are not bracketed one by one: time the call
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             dev.predict_var_dev(q32, kss, 0.0, "float32", "solve")
             b.record()
             torch.cuda.synchronize()
-            k5_s = a.elapsed_time(b) * 1e-3
+            step_ms = np.array([a.elapsed_time(b)])
+        else:
+            whole = (len(k5_ms) // lps) * lps
+            assert whole >= lps and len(k5_ms) == min(64, args.steps * lps), (len(k5_ms), args.steps, lps)
+            step_ms = k5_ms[len(k5_ms) - whole:].reshape(-1, lps).sum(axis=1)
+        k5_s = float(np.mean(step_ms)) * 1e-3
         if method == "inverse_split":
             # every fp32-equivalent multiply-add is six bf16 MFMA multiply-adds (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0)
-            key, peak = "k5_split_kernel", MFMA_BF16_PEAK_TF
-            executed = 6.0 * flops
+            key, peak, per_product = "k5_split_kernel", MFMA_BF16_PEAK_TF, 6.0
             kernel = ("k5_split_kernel<4> (V = W K*^T, fp32 operands as 3 exact bf16 parts, 6 x v_mfma_f32_32x32x16_bf16 per "
                       "32x32x16 block product, fp32 accumulation, fused column-norm epilogue, 1 launch/step)")
         elif method == "inverse_split2":
-            key, peak = "k5_split2_kernel", MFMA_BF16_PEAK_TF        # fp16 MFMA: the same rate as bf16
-            executed = 3.0 * flops
-            kernel = ("k5_split_kernel<4,2,4> (512 x 128 tiles; V = W K*^T, fp32 operands as 2 round-to-nearest fp16 parts, 3 x "
+            key, peak, per_product = "k5_direct_kernel", MFMA_BF16_PEAK_TF, 3.0        # fp16 MFMA: the same rate as bf16
+            kernel = ("k5_direct_kernel<4> (512 x 128 tiles, 128 x 128 per wave, one wave per SIMD; V = W K*^T, fp32 operands as 2 "
+                      "round-to-nearest fp16 parts in fragment order, loaded from L2 straight into registers (no LDS); 3 x "
                       "v_mfma_f32_32x32x16_f16 per 32x32x16 block product, fp32 accumulation, fused column-norm epilogue, "
                       "1 launch/step)")
         else:
-            key, peak = ("gemm_kernel_f32_epi1", MFMA_F32_PEAK_TF)
-            executed = flops
+            key, peak, per_product = "gemm_kernel_f32_epi1", MFMA_F32_PEAK_TF, 1.0
             kernel = ("gemm_kernel<float,false,false,1> (V = W K*^T on v_mfma_f32_32x32x2_f32 with fused column-norm "
                       "epilogue, 1 launch/step)" if method == "inverse" else
                       "gemm_kernel<float,false,true,0> (all launches of the triangular solve)")
         tr = pmc_traffic(key, N, M)
         roof = {"bound": "mfma", "kernel": kernel,
-                "achieved": executed / k5_s / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": executed / k5_s / 1e12 / peak,
+                # `achieved` / `frac` are ALGORITHMIC: N^2 M fp32-equivalent flops over the kernel time, against the dense peak
+                # of the pipe the kernel runs on; `frac_issued` counts the MFMA products actually issued (x 3 / x 6)
+                "achieved": flops / k5_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / k5_s / 1e12 / peak,
+                "frac_algorithmic": flops / k5_s / 1e12 / peak,
+                "frac_issued": per_product * flops / k5_s / 1e12 / peak,
+                "frac_of_fp32_mfma_peak": flops / k5_s / 1e12 / MFMA_F32_PEAK_TF,
                 "pipe": {"inverse_split": "bf16 MFMA", "inverse_split2": "fp16 MFMA"}.get(method, "fp32 MFMA"),
-                "algorithmic_flops_per_launch": executed,
-                "algorithmic_flops_note": "N^2 M fp32-equivalent flops (SURVEY 8d)" +
-                                          {"inverse_split": " x 6 bf16 MFMA products per fp32-equivalent product",
-                                           "inverse_split2": " x 3 fp16 MFMA products per fp32-equivalent product"}.get(method, ""),
-                "fp32_equivalent_TFLOPs": flops / k5_s / 1e12,
+                "algorithmic_flops_per_launch": flops / lps,
+                "issued_flops_per_launch": per_product * flops / lps,
+                "mfma_products_per_fp32_product": per_product,
+                "algorithmic_flops_note": "N^2 M fp32-equivalent flops per step (SURVEY 8d: N^2 per prediction)",
                 "traffic": tr["bytes_per_launch"] if tr else None,
                 "traffic_source": tr["source"] if tr else None,
+                "operand_bytes_per_launch": (float(N) * N * 2 + float(N) * M * 4) if method == "inverse_split2" else None,
                 # committed counter passes of this kernel at this shape (not collected in this process): how busy the matrix
-                # pipe is and the clock the chip holds under it - the product of the two is what `frac` can reach
-                "pmc": ({k: tr[k] for k in ("pmc_mfma_busy", "pmc_clock_ghz", "pmc_source", "zero_operand_frac_of_peak",
-                                            "zero_operand_source") if k in tr} or None) if tr else None,
-                "launches_per_step": 1 if method != "solve" else 2 * (dev.Np // 128) - 1,
-                "kernel_ms": k5_s * 1e3, "kernel_ms_min_max": [float(np.min(k5_ms)), float(np.max(k5_ms))] if len(k5_ms) else None,
-                "timed_launches": int(len(k5_ms)),
+                # pipe is and the clock the chip holds under it - the product of the two is what `frac_issued` can reach
+                "pmc": ({k: tr[k] for k in ("pmc_mfma_busy", "pmc_clock_ghz", "pmc_l2_hit_rate", "pmc_source") if k in tr}
+                        or None) if tr else None,
+                "launches_per_step": lps if method != "solve" else 2 * (dev.Np // 128) - 1,
+                "kernel_ms": k5_s * 1e3, "kernel_ms_min_max": [float(np.min(step_ms)), float(np.max(step_ms))],
+                "timed_launches": int(len(k5_ms)), "timed_steps": int(len(step_ms)),
                 "timing": "HIP events recorded by the library around the launch on its stream, over the timed steps"}
 
     # host-boundary rate (not the headline): queries start in host memory, results end in host memory
@@ -533,9 +550,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             qd = torch.from_numpy(xq_host).to(be.device)
-            mean = dev.predict_mean_dev(qd, y_mean, y_std, "float32")
-            var = dev.predict_var_dev(qd, kss, 0.0, "float32", method)
-            res = torch.cat([mean.double(), var[:, None] * ystd2[None, :]], dim=1).cpu().numpy()
+            res = dev.predict_packed_dev(qd, y_mean, y_std, kss, 0.0, "float32", method).cpu().numpy()
             ts.append(time.perf_counter() - t0)
         host_api = {"ms_per_batch": min(ts) * 1e3, "predictions_per_s": M / min(ts),
                     "note": "PCIe-inclusive: 10 000 x 9 fp32 queries host->HBM, (10 000 x 6) fp64 results HBM->host"}
@@ -614,14 +629,15 @@ def main():
                                       "operand (error class of the fp32 MFMA, checked under \"parity\")"
                                       if (method == "inverse_split" and not c4) else
                                       ("; products on the fp16 MFMA pipe: every fp32 operand as two round-to-nearest fp16 parts "
-                                       "(a0 + a1 = a to 2^-24, fp32's own unit roundoff), block products a1 b0 + a0 b1 + a0 b0 "
-                                       "(error <= 3 x 2^-24 per product, below the fp32 accumulation error; checked under "
+                                       "(a0 + a1 = a to 2^-23 at worst), block products a1 b0 + a0 b1 + a0 b0 (the dropped a1 b1 "
+                                       "is below 2^-22 |a b|; measured error equal to the exact-fp32 MFMA launch's: checked under "
                                        "\"parity\" and, for all three fp32 forms, under \"extras\")"
                                        if (method == "inverse_split2" and not c4) else "")),
                        "parallelism": f"query-sharded x{world}, model replicated (every rank fits redundantly)" +
                                       ((", RCCL all-gather of the means" if c4 else ", RCCL all-gather of [mean|var]")
                                        if use_dist else "")},
             "roofline": roof,
+            "peak_hbm_bytes_per_rank": int(torch.cuda.max_memory_allocated(be.device)),
             "parity": parity,
             "fit": fit,
             "host_api": host_api,
@@ -637,6 +653,12 @@ def main():
                     for k in ("mean", "std", "Xq"):
                         full.pop(k)
                 cb["measured_at_n_train"] = full
+                if "value" in full:          # the host could hold the factor: the measured rate IS the like-for-like figure
+                    cb["extrapolated_value"] = cb["value"]
+                    cb["value"], cb["basis"] = full["value"], "measured"
+                    cb["sample"] = (f"scikit-learn GaussianProcessRegressor.predict(return_std=True) of {full['queries']} queries at "
+                                    f"N_train={N} on a regressor carrying the factor computed on the GPU (downloaded, untimed): "
+                                    f"{full['predict_seconds']:.1f} s on {cb['cores']} threads")
             except Exception as e:  # noqa: BLE001
                 cb["measured_at_n_train"] = {"skipped": repr(e)}
             line["cpu_baseline"] = cb

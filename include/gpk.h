@@ -36,6 +36,9 @@ extern "C" {
 
 typedef struct gpk_context* gpk_handle;
 
+/* the exported entry points (libgpk.so is built with -fvisibility=hidden: nothing else leaves the library) */
+#define GPK_API __attribute__((visibility("default")))
+
 enum { GPK_F32 = 0, GPK_F64 = 1 };
 enum { GPK_OK = 0, GPK_NOT_PD = 1, GPK_BAD_ARG = 2, GPK_HIP_ERROR = 3 };
 /* GPK_MAX_D: features accepted by the Gram kernels (gpk_gram, gpk_cross_gram_t and with them gpk_predict_var*).
@@ -46,16 +49,16 @@ enum { GPK_OK = 0, GPK_NOT_PD = 1, GPK_BAD_ARG = 2, GPK_HIP_ERROR = 3 };
 enum { GPK_TILE = 128, GPK_MAX_D = 64, GPK_MAX_D_PREDICT = 16, GPK_MAX_P = 16, GPK_MAX_BATCH = 8 };
 
 /* ---- context ------------------------------------------------------------------ */
-int gpk_create(gpk_handle* h, int device);
-void gpk_destroy(gpk_handle h);
-const char* gpk_last_error(gpk_handle h);
+GPK_API int gpk_create(gpk_handle* h, int device);
+GPK_API void gpk_destroy(gpk_handle h);
+GPK_API const char* gpk_last_error(gpk_handle h);
 /* Launch on `stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's
  * default stream).  GPK_OWN_STREAM selects the non-blocking stream created by gpk_create, which is
  * what a fresh handle uses.                                                                      */
 #define GPK_OWN_STREAM ((void*)(intptr_t)-1)
-int gpk_set_stream(gpk_handle h, void* stream);
-int gpk_synchronize(gpk_handle h);
-int64_t gpk_padded(int64_t n);
+GPK_API int gpk_set_stream(gpk_handle h, void* stream);
+GPK_API int gpk_synchronize(gpk_handle h);
+GPK_API int64_t gpk_padded(int64_t n);
 
 /* ---- measurement aid -----------------------------------------------------------------------------------
  * gpk_timing(h, 1): from now on the handle brackets its dominant launches with HIP events recorded on the
@@ -65,16 +68,16 @@ int64_t gpk_padded(int64_t n);
  * launches with that tag still in the ring, oldest first (*n_out of them, at most max_n).  bench.py uses it to
  * report the dominant kernel's duration over exactly the timed steps; rocprofv3's kernel trace of the same run is
  * the cross-check.  No reference counterpart (the reference has no instrumentation on this path).        */
-/* gpk_set_option: the tuning knobs a fresh handle reads from the environment (GPK_K5_SPLIT_FORM, GPK_K5_SUPER,
- * GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle: "k5_split_form" (1: 32x32x16
- * MFMAs with register staging, 2: 16x16x32 fused-term MFMAs with LDS filled by DMA - two forms of the one launch behind
- * gpk_predict_var_inv_split, identical products), "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = 512 x 128 tiles when
- * at least 512 of them, 1 = always the 64 x 64-per-wave tiles, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256", "trtri_levels",
- * "gemm_small_tiles".  Used by the A/B timings and by the tests that pin a fast path to its plain form.            */
-int gpk_set_option(gpk_handle h, const char* name, int value);
+/* gpk_set_option: the tuning knobs a fresh handle reads from the environment (GPK_K5_SPLIT2_TILE, GPK_K5_DIRECT_SYNC,
+ * GPK_K5_SUPER, GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle:
+ * "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = the tallest of the 512 / 256 / 128 x 128 tiles that still comes in at
+ * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_direct_sync" (that launch: a workgroup
+ * barrier every so many k-tiles, 0 = never), "k5_super", "small_path", "trsm256", "trtri_levels", "gemm_small_tiles",
+ * "k3_stream_min_np".  Used by the A/B timings and by the tests that pin a fast path to its plain form.            */
+GPK_API int gpk_set_option(gpk_handle h, const char* name, int value);
 enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2 };
-int gpk_timing(gpk_handle h, int enable);
-int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out);
+GPK_API int gpk_timing(gpk_handle h, int enable);
+GPK_API int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out);
 
 /* ---- batched mode: `count` (<= 8) same-shaped problems per call --------------------------------------
  * Between gpk_batch_begin and gpk_batch_end, gpk_potrf, gpk_leaf_inverses, gpk_trtri, gpk_wtw and
@@ -84,10 +87,10 @@ int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out);
  * other pointer is shared by all problems.  gpk_potrf's `info` then receives `count` entries.
  * (BASELINE configuration 5: the per-axis ax/ay/az GPs of src/px4/gp_trainer.py:139-179 factorised
  * together.)                                                                                          */
-int gpk_batch_begin(gpk_handle h, int count);
-int gpk_batch_buffer(gpk_handle h, const void* base, int64_t stride_bytes);
-int gpk_batch_end(gpk_handle h);
-const char* gpk_version(void);
+GPK_API int gpk_batch_begin(gpk_handle h, int count);
+GPK_API int gpk_batch_buffer(gpk_handle h, const void* base, int64_t stride_bytes);
+GPK_API int gpk_batch_end(gpk_handle h);
+GPK_API const char* gpk_version(void);
 
 /* ---- K1: RBF Gram build ---------------------------------------------------------
  * K[i][j] = sf2 * exp(-0.5 * sum_d ((x_id - x_jd) / ls_d)^2), exact differences,
@@ -97,7 +100,7 @@ const char* gpk_version(void);
  * squareform), :1402 (WhiteKernel diag), sklearn/gaussian_process/_gpr.py:347 (alpha
  * jitter); quadrotor_gp_mpc/quadrotor_gp_mpc/gaussian_process.py:158-171.
  * X: dev (N x D), ls: host double[D], K: dev (Np x ldk), ldk >= Np.                  */
-int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+GPK_API int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
              double sf2, double diag_add, void* K, int64_t ldk);
 
 /* Row slab of the same matrix, for a Gram build sharded over GPUs by rows (no exchange: rank r writes the rows it
@@ -105,14 +108,14 @@ int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D, const dou
  * receives rows row0 .. row0 + gpk_padded(nrows) - 1 of the padded matrix gpk_gram would write - every entry computed
  * directly (no symmetric mirroring across slabs), diagonal = sf2 + diag_add, identity in the padding.  row0 % 128 == 0.
  * Replaces the same reference lines as gpk_gram.                                                                    */
-int gpk_gram_rows(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls, double sf2,
+GPK_API int gpk_gram_rows(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls, double sf2,
                   double diag_add, int64_t row0, int64_t nrows, void* Kslab, int64_t ldk);
 
 /* Cross kernel, transposed layout: B[j][m] = sf2 * exp(-0.5 ||(x_j - xq_m)/ls||^2) for
  * j < N, m < M; zero elsewhere in the (Np x Mp) padded block.  No white noise.
  * Replaces: sklearn/gaussian_process/kernels.py:1564-1565 (cdist + exp).
  * X dev (N x D), Xq dev (M x D), B dev (Np x ldb), ldb >= Mp = gpk_padded(M).          */
-int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t N, const void* Xq,
+GPK_API int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t N, const void* Xq,
                      int64_t M, int D, const double* ls, double sf2, void* B, int64_t ldb);
 
 /* ---- K2: blocked Cholesky --------------------------------------------------------
@@ -123,26 +126,26 @@ int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t N, const vo
  * *info (host) = 0, or the 1-based index of the first non-positive pivot (GPK_NOT_PD).
  * Synchronises.  Replaces: scipy.linalg.cholesky(K, lower=True) at
  * sklearn/gaussian_process/_gpr.py:349,587; gaussian_process.py:184.                  */
-int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int* info);
+GPK_API int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int* info);
 
 /* Recompute winv (inverses of the 128x128 diagonal blocks) from an existing padded factor L,
  * e.g. one imported from a scikit-learn pickle (L_ at sklearn/gaussian_process/_gpr.py:349). */
-int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int64_t ldl, double* winv);
+GPK_API int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int64_t ldl, double* winv);
 
 /* Convert the lower triangle of L and winv to fp32 copies (for the fp32 predict path). */
-int gpk_factor_to_f32(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+GPK_API int gpk_factor_to_f32(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
                       float* Lf, int64_t ldlf, float* winvf);
 
 /* ---- K3: alpha = L^-T (L^-1 Y) -----------------------------------------------------
  * Y: dev (N x P) row-major fp64 (already normalised), alpha: dev (N x P).  P <= GPK_MAX_P.
  * Replaces: cho_solve((L, True), y) at sklearn/gaussian_process/_gpr.py:360-364,597;
  * gaussian_process.py:187-189.                                                          */
-int gpk_potrs(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+GPK_API int gpk_potrs(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
               const double* Y, int64_t N, int P, double* alpha);
 
 /* K3 through the explicit inverse factor W = L^-1 (gpk_trtri): alpha = W^T (W Y), two GEMM launches
  * that each stream W once, instead of the 4 Np/128 - 2 launches of the recursive solve.              */
-int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const double* Y, int64_t N,
+GPK_API int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const double* Y, int64_t N,
                   int P, double* alpha);
 
 /* ---- K5 building blocks: B <- L^-1 B, and column sums of squares ---------------------
@@ -150,10 +153,10 @@ int gpk_potrs_inv(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const 
  * (L, winv and B must all have that dtype).
  * Replaces: solve_triangular(L_, K_trans.T, lower=True) at sklearn/_gpr.py:454-456 and
  * the einsum at :477.                                                                    */
-int gpk_trsm_lower_left(gpk_handle h, int dtype, const void* L, int64_t Np, int64_t ldl,
+GPK_API int gpk_trsm_lower_left(gpk_handle h, int dtype, const void* L, int64_t Np, int64_t ldl,
                         const void* winv, void* B, int64_t Mp, int64_t ldb);
 /* out[m] = sum_{i < Np} B[i][m]^2, accumulated in fp64; out: dev double[Mp].              */
-int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, int64_t Mp, int64_t ldb,
+GPK_API int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, int64_t Mp, int64_t ldb,
                  double* out);
 
 /* ---- K4: fused posterior mean -----------------------------------------------------------
@@ -163,7 +166,7 @@ int gpk_colsumsq(gpk_handle h, int dtype, const void* B, int64_t Np, int64_t Mp,
  * Queries must be finite (the host side validates them as scikit-learn does; a NaN coordinate gives k* = 0).
  * Replaces: sklearn/gaussian_process/_gpr.py:441-447 (K_trans @ alpha_, undo normalisation);
  * the 25-call loop at src/px4/mpc.py:1490-1506; gaussian_process.py:223-226.              */
-int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
+GPK_API int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
                      int P, const double* ls, double sf2, const double* y_mean,
                      const double* y_std, const void* Xq, int64_t M, void* mean);
 
@@ -179,7 +182,7 @@ int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const void* alpha, 
  * Up to 32 queries (D, P <= 16, N <= 16384) take two dedicated launches (K* + mean shares; 16 rows of W per
  * workgroup on the fp64 MFMA, last-workgroup reductions) instead of the general chain's seven.           */
 #define GPK_HOST_MAX_M 4096
-int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P,
+GPK_API int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t N, int D, int P,
                      const double* ls, double sf2, const double* y_mean, const double* y_std,
                      const double* W, int64_t Np, int64_t ldw, double kss, double floor_,
                      const double* Xq_host, int64_t M, double* mean_host, double* var_host);
@@ -190,7 +193,7 @@ int gpk_predict_host(gpk_handle h, const double* X, const double* alpha, int64_t
  * B (host).  1 <= M <= 32, D <= 16, N <= 16384.  mean_host: B x M (un-normalised); var_host: B x M in
  * normalised-target units, or NULL (then W and kss may be NULL).
  * Replaces: the loop over six scalar GPs of src/px4/pretrained_gp.py:52-98.                                 */
-int gpk_predict_host_multi(gpk_handle h, int B, const double* const* X, const double* const* alpha, int64_t N, int D,
+GPK_API int gpk_predict_host_multi(gpk_handle h, int B, const double* const* X, const double* const* alpha, int64_t N, int D,
                            const double* ls, const double* sf2, const double* y_mean, const double* y_std,
                            const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
                            const double* Xq_host, int64_t M, double* mean_host, double* var_host);
@@ -202,7 +205,7 @@ int gpk_predict_host_multi(gpk_handle h, int B, const double* const* X, const do
  * training mean); the expansion is accurate to ~|u|^2 * 2^-23 in the exponent, u = (x - center) / ls, so
  * callers use it while max |u|^2 is modest (device.py: <= 64) and the exact-difference kernel otherwise.
  * D <= 16, P <= 8.  Replaces the same reference lines as gpk_predict_mean.                              */
-int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,
+GPK_API int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,
                           const double* ls, double sf2, const double* center, const double* y_mean,
                           const double* y_std, const float* Xq, int64_t M, float* mean);
 
@@ -216,40 +219,56 @@ int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* alpha, int6
  * accumulation; the dropped terms are below 2^-24 of |a||b|).  work: dev float[Mp * Np] (K* in fp32),
  * work3: dev, Mp * Np * 6 bytes (its split); var: dev double[Mp].  X, Xq fp32.
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485).       */
-int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst);
-int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+GPK_API int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, void* dst);
+GPK_API int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
                               const void* W3, int64_t Np, const float* Xq, int64_t M, double kss, double floor_,
                               float* work, void* work3, double* var);
 
-/* The same launch with an fp16 x 2 operand split, three products per block.
- * gpk_split2: src (dev rows x ld fp32) -> dst (dev, rows * cols * 4 bytes): x * scale = h0 + h1 (+ a remainder below
- * 2^-24 |x|) with h0, h1 fp16 rounded to nearest, chunk order [row / 4][k16 block][row % 4][half][part]; `scale` is a power of two chosen
- * by the caller so that max |x * scale| <= 2^15 (it puts the operand at the top of fp16's range; entries more than
- * 2^-12 below the largest lose relative - not absolute - precision).
- * gpk_predict_var_inv_split2: as gpk_predict_var_inv_split with W2 = gpk_split2(fp32 inverse factor, w_scale); K* is
- * scaled by the power of two below 2^15 / sf2 internally; block products are a1 b0 + a0 b1 + a0 b0 on
- * v_mfma_f32_32x32x16_f16, fp32 accumulation: half the matrix-pipe work of the bf16 x 3 split.  With round-to-nearest
- * parts a0 + a1 reproduces a to 2^-24 (fp32's unit roundoff) and the dropped a1 b1 is below 2^-24 |a b|: at most
- * 3 x 2^-24 per product, below what the fp32 accumulation adds; measured over 31 random models the error of
- * |W k*|^2 equals that of the exact-fp32 MFMA launch (profiles/r02_fp32_variance_forms_accuracy.log).  The fp32 default
- * of the Python host side and of gpk_predict.  work: dev float[Mp * Np]; work2: dev, Mp * Np * 4 bytes; var: dev
- * double[Mp].
+/* The same launch with an fp16 x 2 operand split, three products per block, both operands in "fragment order" and one
+ * scale per 128-row block of W (the fp32 serving default of the Python host side and of gpk_predict).
+ * gpk_split2_rows: W (dev n x ld fp32 inverse factor, gpk_tril_to_f32 output, n % 128 == 0) -> scales (dev float[n / 128]:
+ * for each 128-row block the largest power of two s with s * max |W_ij| <= 2^15, the maximum taken over the block's part of
+ * the lower triangle - computed on the device, no synchronisation) and dst (dev, n * n * 4 bytes): x s = h0 + h1 + r with
+ * h0, h1 fp16 rounded to nearest, |r| <= 2^-23 |x s| while h1 is a normal number (entries within 2^-18 of their row
+ * block's largest) and |r| <= 2^-25 absolutely below that; 16-byte chunks in fragment order: chunk (row, k16 block kb,
+ * k half h, part p) at index (((row / 32) * (n / 16) + kb) * 2 + p) * 64 + h * 32 + row % 32 - the 64 chunks of one
+ * v_mfma_f32_32x32x16_f16 operand are 1 KiB of contiguous memory.
+ * gpk_predict_var_inv_split2: the result of gpk_predict_var_inv(GPK_F32, ...) from W2 / w_scales = gpk_split2_rows of the
+ * fp32 inverse factor: K* (scaled by the power of two below 2^15 / sf2) is computed straight into the same layout
+ * (work2: dev, Mp * Np * 4 bytes; no fp32 panel exists), and ONE launch forms V = W K*^T on the fp16 matrix pipe - block
+ * products a1 b0 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16, fp32 accumulation: half the matrix-pipe work of the bf16 x 3
+ * split - with every operand fragment loaded from L2 straight into registers (no LDS), reduced to column sums of squares
+ * in its epilogue.  With round-to-nearest parts a0 + a1 reproduces a to 2^-23 at worst and the dropped a1 b1 is below
+ * 2^-22 |a b|; measured over 31 random models the error of |W k*|^2 equals that of the exact-fp32 MFMA launch
+ * (profiles/r02_fp32_variance_forms_accuracy.log).  var: dev double[Mp].  D <= 16.
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485).                  */
-int gpk_split2(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, double scale, void* dst);
-/* *out (host) = max |A_ij| over the lower triangle of the fp32 matrix A (dev n x lda): what the caller derives the
- * scale of gpk_split2 from for an inverse factor (scale = the largest power of two with scale * max <= 2^15).
- * Synchronises.                                                                                                    */
-int gpk_tril_absmax(gpk_handle h, const float* A, int64_t n, int64_t lda, double* out);
-int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
-                               const void* W2, double w_scale, int64_t Np, const float* Xq, int64_t M, double kss,
-                               double floor_, float* work, void* work2, double* var);
+GPK_API int gpk_split2_rows(gpk_handle h, const float* W, int64_t n, int64_t ld, float* scales, void* dst);
+GPK_API int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+                                       const void* W2, const float* w_scales, int64_t Np, const float* Xq, int64_t M,
+                                       double kss, double floor_, void* work2, double* var);
+
+/* One fp32 serving step in one call, the whole result in one buffer: out (dev double, M x 2P) row m =
+ * [mean[m][0..P) | var[m] y_std[p]^2, p = 0..P) - K4 (gpk_predict_mean_mfma when `center` is given, else
+ * gpk_predict_mean(GPK_F32)) into mean_tmp (dev float[M * P]), then gpk_predict_var_inv_split2's launch with the variance's
+ * un-normalisation (sklearn/gaussian_process/_gpr.py:487-489) and the packing folded into its finalising kernel; that
+ * kernel also adds to *low_count (dev, nullable; the caller zeroes it) the number of rows whose normalised variance is
+ * below `recheck_below` - the rows the fp32 serving gate recomputes in fp64.
+ * gpk_pack_mean_var: the same rows from a separate mean (dev M x P of `dtype`) and normalised variance (dev double[M]) -
+ * for the serving paths whose variance comes from another launch.  P <= 16.                                          */
+GPK_API int gpk_predict_mean_var_split2(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,
+                                        const double* ls, double sf2, const double* center, const double* y_mean,
+                                        const double* y_std, const void* W2, const float* w_scales, int64_t Np,
+                                        const float* Xq, int64_t M, double kss, double floor_, void* work2,
+                                        float* mean_tmp, double recheck_below, unsigned* low_count, double* out);
+GPK_API int gpk_pack_mean_var(gpk_handle h, int dtype, const void* mean, const double* var, int64_t M, int P,
+                              const double* y_std, double* out);
 
 /* K4 for B (<= 8) independent single-output ARD models that share X (the per-axis GPs of
  * src/px4/gp_trainer.py:139-179, predicted one by one at src/px4/pretrained_gp.py:64-91): one launch
  * evaluates every model; the feature differences of a (query, training point) pair are formed once.
  * alpha: dev (N x B), column b = model b; ls: host double[B*D] (row b = model b's ARD length-scales);
  * sf2, y_mean, y_std: host double[B]; mean: dev (M x B).  X, alpha, Xq, mean of `dtype`.  D <= 16.      */
-int gpk_predict_mean_multi(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
+GPK_API int gpk_predict_mean_multi(gpk_handle h, int dtype, const void* X, const void* alpha, int64_t N, int D,
                            int B, const double* ls, const double* sf2, const double* y_mean,
                            const double* y_std, const void* Xq, int64_t M, void* mean);
 
@@ -259,7 +278,7 @@ int gpk_predict_mean_multi(gpk_handle h, int dtype, const void* X, const void* a
  * work: dev scratch of at least Np * Mp elements of `dtype` (Mp = gpk_padded(M)).
  * var: dev double[Mp] (only the first M entries are meaningful).
  * Replaces: sklearn/gaussian_process/_gpr.py:454-485; gaussian_process.py:229-232.          */
-int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+GPK_API int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
                     double sf2, const void* L, int64_t Np, int64_t ldl, const void* winv,
                     const void* Xq, int64_t M, double kss, double floor, void* work,
                     double* var);
@@ -278,27 +297,27 @@ int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, int D, co
  * of Mp * Np elements of `dtype`; var: dev double[M] (only M entries are written).
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485),
  * with solve_triangular(L, K*^T) evaluated as (L^-1) K*^T.                                          */
-int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
+GPK_API int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
               int64_t ldw, double* work);
-int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_t lda, float* Af, int64_t ldaf);
-int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
+GPK_API int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_t lda, float* Af, int64_t ldaf);
+GPK_API int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
                         double sf2, const void* W, int64_t Np, int64_t ldw, const void* Xq, int64_t M,
                         double kss, double floor, void* work, double* var);
 
 /* ---- K6a: log-marginal-likelihood terms -----------------------------------------------------
  * terms[0] = sum_{i<N} log L[i][i]; terms[1 + p] = sum_i Y[i][p] * alpha[i][p]  (host doubles).
  * Synchronises.  Replaces: sklearn/gaussian_process/_gpr.py:609-613; gaussian_process.py:250-261. */
-int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y,
+GPK_API int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y,
                   const double* alpha, int P, double* terms);
 
 /* ---- K6b: K^-1 and the fused LML-gradient reduction --------------------------------------------
  * gpk_potri: Kinv (dev Np x ldk) <- lower triangle of (L L^T)^-1 (trtri + W^T W on fp64 MFMA).
  * L is not modified.  work: dev double[Np * Np].
  * Replaces: cho_solve((L, True), eye(N)) at sklearn/gaussian_process/_gpr.py:627-629.           */
-int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
+GPK_API int gpk_potri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv,
               double* Kinv, int64_t ldk, double* work);
 /* The second half of gpk_potri when W = L^-1 is already at hand: Kinv (lower tiles) = W^T W.       */
-int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, double* Kinv, int64_t ldk);
+GPK_API int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, double* Kinv, int64_t ldk);
 /* grad[d] (d < D) = 0.5 * sum_ij Q_ij K_ij ((x_id - x_jd)/ls_d)^2, grad[D] = 0.5 * noise * tr(Q),
  * Q = alpha alpha^T - P * Kinv, K_ij = sf2 exp(-0.5 d2_ij) recomputed on the fly (the
  * N x N x D tensor sklearn builds at kernels.py:1576-1579 is never materialised).
@@ -306,7 +325,7 @@ int gpk_wtw(gpk_handle h, const double* W, int64_t Np, int64_t ldw, double* Kinv
  * (the signal-variance gradient used by the package GP).  D <= 16.  Synchronises.
  * Replaces: sklearn/gaussian_process/_gpr.py:615-647 + sklearn/gaussian_process/kernels.py:1571-1580,
  * :1403-1408.                                                                                     */
-int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2,
+GPK_API int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2,
                  double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
                  double* grad);
 
@@ -340,15 +359,15 @@ int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* 
  *   scikit-learn's L_), alpha (N x P), y_mean / y_std (P) - e.g. to write or read the reference's model files
  *   (src/px4/train_gp_offline.py:188-194; gaussian_process.py:369-394 stores the training set and refits).  NULL
  *   outputs are skipped.  An imported model predicts; gpk_lml(theta) needs a fitted one.                        */
-int gpk_fit(gpk_handle h, const double* X, int64_t N, int D, const double* Y, int P, const double* ls, int n_ls,
+GPK_API int gpk_fit(gpk_handle h, const double* X, int64_t N, int D, const double* Y, int P, const double* ls, int n_ls,
             double sf2, double noise, double jitter, int normalize_y);
-int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, void* var, int dtype, int var_includes_noise);
-int gpk_lml(gpk_handle h, const double* theta, int n_theta, double* lml, double* grad);
-int gpk_export(gpk_handle h, int64_t* N, int* D, int* P, double* L, double* alpha, double* y_mean, double* y_std,
+GPK_API int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, void* var, int dtype, int var_includes_noise);
+GPK_API int gpk_lml(gpk_handle h, const double* theta, int n_theta, double* lml, double* grad);
+GPK_API int gpk_export(gpk_handle h, int64_t* N, int* D, int* P, double* L, double* alpha, double* y_mean, double* y_std,
                double* lml);
-int gpk_import(gpk_handle h, const double* X, int64_t N, int D, const double* L, const double* alpha, int P,
+GPK_API int gpk_import(gpk_handle h, const double* X, int64_t N, int D, const double* L, const double* alpha, int P,
                const double* ls, int n_ls, double sf2, double noise, const double* y_mean, const double* y_std);
-int gpk_model_release(gpk_handle h);
+GPK_API int gpk_model_release(gpk_handle h);
 
 /* ---- composite calls for B (<= GPK_MAX_BATCH) single-output models on shared inputs ----------------------------
  * The per-axis layout of src/px4/gp_trainer.py:139-179 (one scalar GP per residual component, each with its own ARD
@@ -371,10 +390,10 @@ int gpk_model_release(gpk_handle h);
  *   hyper-parameter step of all per-axis models at once).  A model whose trial matrix is not positive definite gets
  *   lml = -inf, grad = 0.  Replaces: B evaluations of log_marginal_likelihood, _gpr.py:537-652.
  * gpk_model_release frees this object too.                                                                         */
-int gpk_fit_batched(gpk_handle h, int B, const double* X, int64_t N, int D, const double* Y, const double* ls, int n_ls,
+GPK_API int gpk_fit_batched(gpk_handle h, int B, const double* X, int64_t N, int D, const double* Y, const double* ls, int n_ls,
                     const double* sf2, const double* noise, double jitter, int normalize_y, int* info);
-int gpk_predict_batched(gpk_handle h, const double* Xq, int64_t M, double* mean, double* var, int var_includes_noise);
-int gpk_lml_batched(gpk_handle h, const double* thetas, int n_theta, double* lml, double* grad);
+GPK_API int gpk_predict_batched(gpk_handle h, const double* Xq, int64_t M, double* mean, double* var, int var_includes_noise);
+GPK_API int gpk_lml_batched(gpk_handle h, const double* thetas, int n_theta, double* lml, double* grad);
 
 /* ---- building block: whole-tile GEMM on the matrix cores ---------------------------------------
  * C[m x n] = alpha * opA(A) * opB(B)^T + beta * C, m and n multiples of 128, k a multiple of 16
@@ -384,7 +403,7 @@ int gpk_lml_batched(gpk_handle h, const double* thetas, int n_theta, double* lml
  * it is exported so that it can be tested and timed on its own (fp64 via v_mfma_f64_16x16x4_f64,
  * fp32 via v_mfma_f32_32x32x2_f32).  No reference counterpart other than the BLAS-3 calls inside
  * LAPACK's dpotrf/dtrsm (SciPy, sklearn/gaussian_process/_gpr.py:349,454).                          */
-int gpk_gemm_tiles(gpk_handle h, int dtype, int ta, int tb, const void* A, int64_t lda, const void* B,
+GPK_API int gpk_gemm_tiles(gpk_handle h, int dtype, int ta, int tb, const void* A, int64_t lda, const void* B,
                    int64_t ldb, void* C, int64_t ldc, int64_t m, int64_t n, int64_t k, double alpha,
                    double beta, int lower_only);
 

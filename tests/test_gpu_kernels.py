@@ -430,18 +430,49 @@ def test_split3_is_exact(be):
     assert np.all(x1 <= x0 * 2.0 ** -8 + 1e-45) and np.all(x2 <= x0 * 2.0 ** -16 + 1e-45)
 
 
-@pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300), (8192, 4200)])
-def test_variance_bf16_split_path(be, N, M, form):
-    """K5 with the exact bf16x3 operand split (six bf16 MFMAs per fp32 block product) against the fp64 path and
-    the fp32-MFMA path on the same queries: the same fp32 accuracy class (std within 1e-3 of fp64 - the stated
-    fp32 tolerance - and within 2x of the fp32-MFMA path's own error), in super-tile mode (N = 5000: 40 x 2 tiles
-    is direct; N = 3000 x 700: 24 x 6) and with ragged sizes (N = 8192 x 4200: 16 x 33 tiles of 512 x 128 - the library's own
-    rule picks the large-tile fp16 x 2 kernel there).  Both forms of the launch (gpk_set_option
-    "k5_split_form": 32x32x16 MFMAs with register staging / 16x16x32 fused-term MFMAs with LDS filled by DMA; the second
-    serves padded sizes that are multiples of 256 - N = 2500 pads to 2560 - and falls back to the first otherwise)."""
+def test_split2_rows_layout_and_scales(be):
+    """gpk_split2_rows: per 128-row block the largest power of two s with s * max |W_ij| (lower triangle) <= 2^15, and
+    every entry x as two fp16 parts with x s = h0 + h1 to 2^-23 (entries within 2^-18 of the block's largest), stored in
+    fragment order: chunk (row, k16 block kb, k half h, part p) at (((row / 32) * KB + kb) * 2 + p) * 64 + h * 32 + row % 32."""
+    import torch
+    n = 384
+    g = torch.Generator(device="cpu").manual_seed(5)
+    W = torch.randn((n, n), generator=g) * torch.exp(2.0 * torch.randn((n, n), generator=g))
+    W[128:256] *= 2.0 ** -9                  # a row block of much smaller entries gets its own, larger scale
+    W[300, 17] = 4096.0                      # exactly a power of two: the scale puts it AT 2^15
+    W = torch.tril(W) + torch.triu(torch.full((n, n), 1.0e30), 1)     # what lies above the diagonal must not count
+    Wd = W.to(be.device).contiguous()
+    scales = torch.zeros((n // 128,), dtype=torch.float32, device=be.device)
+    dst = torch.zeros((n * n * 4,), dtype=torch.uint8, device=be.device)
+    be.bind_stream()
+    be.check(be.lib.gpk_split2_rows(be.h, _p(Wd), n, n, _p(scales), _p(dst)))
+    sc = scales.cpu().numpy().astype(np.float64)
+    Wl = np.tril(W.numpy().astype(np.float64))
+    for b in range(n // 128):
+        m = np.abs(Wl[128 * b:128 * b + 128]).max()
+        assert sc[b] == 2.0 ** np.floor(np.log2(32768.0 / m)), (b, sc[b], m)
+        assert 16384.0 < sc[b] * m <= 32768.0
+    assert sc[2] * 4096.0 == 32768.0 and sc[1] > sc[0]
+    raw = dst.cpu().numpy().view(np.float16).reshape(n // 32, n // 16, 2, 2, 32, 8)      # [rb][kb][part][h][r][j]
+    parts = np.moveaxis(raw, 4, 1)                                                          # [rb][r][kb][part][h][j]
+    tot = (parts[:, :, :, 0].astype(np.float64) + parts[:, :, :, 1].astype(np.float64)).reshape(n, n)   # [row][16 kb + 8 h + j]
+    want = Wl * sc[np.arange(n) // 128, None]
+    low = np.tril(np.ones((n, n), dtype=bool))
+    rowmax = np.abs(want).max(axis=1, keepdims=True)
+    big = low & (np.abs(want) >= rowmax * 2.0 ** -18)
+    assert np.all(np.abs(tot - want)[big] <= 2.0 ** -23 * np.abs(want)[big])
+    assert np.all(np.abs(tot - want)[low & ~big] <= 2.0 ** -25)
+
+
+@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300), (8192, 4200), (4096, 16500)])
+def test_variance_16bit_split_paths(be, N, M):
+    """K5 on the 16-bit matrix pipe against the fp64 path and the exact-fp32 MFMA path on the same queries: the bf16 x 3
+    split (six exact products per block) and the fp16 x 2 split (three products; the fp32 default) are in the same fp32
+    accuracy class - std within 1e-3 of fp64 (the stated fp32 tolerance) and within 2x of the fp32-MFMA path's own
+    error - in super-tile mode (N = 5000: 40 x 2 tiles is direct; N = 3000 x 700: 24 x 6), with ragged sizes, and for every
+    tile height of the fp16 x 2 launch (option "k5_split2_tile": 128-row tiles, forced 512-row tiles where Np % 512 == 0,
+    and the library's own rule - N = 4096 x 16500 queries: 8 x 129 tiles of 512 rows)."""
     from unmanned_aerial_vehicles_amd.device import DeviceGP
-    be.check(be.lib.gpk_set_option(be.h, b"k5_split_form", form))
     rng = np.random.default_rng(N)
     X = rng.standard_normal((N, 9))
     Y = np.sin(X @ rng.standard_normal((9, 2))) + 0.1 * rng.standard_normal((N, 2))
@@ -452,27 +483,21 @@ def test_variance_bf16_split_path(be, N, M, form):
     v64 = dev.predict_var_dev(Xq, 1.05, 0.0, "float64", "inverse").cpu().numpy()
     v32 = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse").cpu().numpy()
     vsp = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split").cpu().numpy()
-    e32 = np.max(np.abs(np.sqrt(v32) - np.sqrt(v64)) / np.sqrt(v64))
-    esp = np.max(np.abs(np.sqrt(vsp) - np.sqrt(v64)) / np.sqrt(v64))
-    be.check(be.lib.gpk_set_option(be.h, b"k5_split_form", 1))
+    err = lambda v: np.max(np.abs(np.sqrt(v) - np.sqrt(v64)) / np.sqrt(v64))  # noqa: E731
+    e32, esp = err(v32), err(vsp)
     assert esp < 1e-3 and esp < 2.0 * e32 + 1e-6, (e32, esp)
-    if form == 1:
-        # the fp16 x 2 form (three products per block; the fp32 default): the same accuracy class as the exact forms
-        vs2 = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
-        es2 = np.max(np.abs(np.sqrt(vs2) - np.sqrt(v64)) / np.sqrt(v64))
-        assert es2 < 1e-3 and es2 < 2.0 * e32 + 1e-6, (e32, es2)
-        # its two tile configurations (64 x 64 per wave / 128 x 64 per wave in 512 x 128 tiles - the large-problem
-        # default, forced here; padded sizes that are not multiples of 512 keep the first): the same products, only the
-        # order of the epilogue's fp32 column sums differs
-        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 2))
-        vs2b = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
-        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 1))
-        vs2c = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
-        be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 0))
-        assert np.array_equal(vs2, vs2b if (dev.Np // 512) * (-(-M // 128)) >= 512 and dev.Np % 512 == 0 else vs2c)     # the rule
-        assert np.max(np.abs(vs2b - vs2c)) <= 4e-6 * np.max(np.abs(vs2c))
-        w2, sc = dev.split2_inverse_factor()
-        assert sc == 2.0 ** round(np.log2(sc)) and 16384.0 < sc * float(np.abs(np.tril(dev.inverse_factor(True).cpu().numpy())).max()) <= 32768.0
+    vs2 = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
+    assert err(vs2) < 1e-3 and err(vs2) < 2.0 * e32 + 1e-6, (e32, err(vs2))
+    # the tile heights of the fp16 x 2 launch: the same products in the same order, only the grouping of the epilogue's
+    # fp32 column sums differs
+    be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 2))
+    vs2b = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
+    be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 1))
+    vs2c = dev.predict_var_dev(Xq, 1.05, 0.0, "float32", "inverse_split2").cpu().numpy()
+    be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 0))
+    assert np.max(np.abs(vs2b - vs2c)) <= 4e-6 * np.max(np.abs(vs2c)) and np.max(np.abs(vs2 - vs2c)) <= 4e-6 * np.max(np.abs(vs2c))
+    if dev.Np % 512 == 0 and (dev.Np // 512) * (-(-M // 128)) >= 512:
+        assert np.array_equal(vs2, vs2b)                                                    # the rule picked 512-row tiles
     with pytest.raises(ValueError):
         dev.predict_var_dev(Xq, 1.05, 0.0, "float64", "inverse_split")
 

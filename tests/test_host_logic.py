@@ -185,6 +185,29 @@ def test_add_training_data_vs_reference_fixture(loader_ref):
     assert np.array_equal(np.array(small.X_train), loader_ref["atd_small_X"])  # deque eviction (simple_gp.py:31-32)
 
 
+def test_load_training_data_vs_reference_fixture(tmp_path):
+    """`GPTrainer.load_training_data` against the reference method's own output (tests/golden/flight_ref.npz, written by
+    make_golden_r3.py from `src/px4/gp_trainer.py:49-119` on synthetic flight_data_*.npz files): [state, control] rows,
+    double-integrator residuals, and the seeded `max_samples` draw from the global NumPy RNG - bit for bit."""
+    from conftest import GOLDEN
+    from unmanned_aerial_vehicles_amd.trainer import GPTrainer
+    ref = np.load(os.path.join(GOLDEN, "flight_ref.npz"))
+    for k in range(int(ref["n_files"])):
+        np.savez(tmp_path / f"flight_data_{k}.npz", **{key: ref[f"file{k}_{key}"] for key in
+                                                       ("states_prev", "controls", "states_next", "dt_values")})
+    tr = GPTrainer(data_dir=str(tmp_path), model_dir=str(tmp_path))
+    X, y = tr.load_training_data()
+    assert X.shape == ref["X"].shape and y.shape == ref["y"].shape == (X.shape[0], 6)
+    assert np.array_equal(X, ref["X"]) and np.array_equal(y, ref["y"])
+    np.random.seed(int(ref["seed"]))
+    Xs, ys = tr.load_training_data(max_samples=int(ref["max_samples"]))
+    assert np.array_equal(Xs, ref["X_sub"]) and np.array_equal(ys, ref["y_sub"])
+    X2, _ = tr.load_training_data(max_samples=10 ** 6)            # more than there is: everything, in order
+    assert np.array_equal(X2, ref["X"])
+    with pytest.raises(FileNotFoundError):
+        GPTrainer(data_dir=str(tmp_path / "empty"), model_dir=str(tmp_path)).load_training_data()
+
+
 def test_pretrained_gp_never_raises(tmp_path, trainer_ref):
     """`PreTrainedGP` on a pickle whose models are foreign objects (what the reference's gp_trainer.py writes):
     loading and predicting never raise; without a GPU every component falls back to (0, 1e6)

@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libgpk.so")
 SOURCES = ["gpk_api.hip", "gpk_gram.hip", "gpk_gemm.hip", "gpk_chol.hip", "gpk_grad.hip", "gpk_mean.hip", "gpk_k5split.hip", "gpk_small.hip",
            "gpk_model.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _stale():

@@ -38,10 +38,11 @@ SIGNATURES = {
     "gpk_export": (_int, [_vp, C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int), _dp, _dp, _dp, _dp, _dp]),
     "gpk_import": (_int, [_vp, _dp, _i64, _int, _dp, _dp, _int, _dp, _int, _dbl, _dbl, _dp, _dp]),
     "gpk_model_release": (_int, [_vp]),
-    "gpk_split2": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _vp]),
-    "gpk_tril_absmax": (_int, [_vp, _vp, _i64, _i64, C.POINTER(C.c_double)]),
-    "gpk_predict_var_inv_split2": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _vp, _dbl, _i64, _vp, _i64, _dbl, _dbl, _vp,
-                                          _vp, _vp]),
+    "gpk_split2_rows": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gpk_predict_var_inv_split2": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _vp, _vp]),
+    "gpk_predict_mean_var_split2": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _dp, _vp, _vp, _i64, _vp, _i64,
+                                           _dbl, _dbl, _vp, _vp, _dbl, _vp, _vp]),
+    "gpk_pack_mean_var": (_int, [_vp, _int, _vp, _vp, _i64, _int, _dp, _vp]),
     "gpk_set_option": (_int, [_vp, C.c_char_p, _int]),
     "gpk_timing": (_int, [_vp, _int]),
     "gpk_kernel_times": (_int, [_vp, _int, _dp, _int, C.POINTER(_int)]),

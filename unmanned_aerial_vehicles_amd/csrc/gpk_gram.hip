@@ -304,22 +304,22 @@ __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, l
   }
 }
 
-// ---- K* written straight into the fp16 x 2 split layout of the variance launch ------------------------
+// ---- K* written straight into the fp16 x 2 fragment-order layout of the variance launch ------------------------
 // Kq[q][j] = sf2 exp(-0.5 |xq_q - x_j|^2) (query-major, j = training point = the k index of V = W Kq^T), zero in the
-// padding, never stored as fp32: a lane computes the eight values of one (query, k-half) and writes their two fp16
-// parts as two adjacent 16-byte chunks of the layout [q / 4][k16 block][q % 4][half][part] (gpk_split2) - the
-// separate fp32 panel (2.65 GB at the headline shape) and the pass that split it (2.65 GB read + 2.65 GB written) are
-// gone.  Same arithmetic per entry as cross_t_kernel (exact differences of the length-scale-divided coordinates,
-// FMA accumulation, exp_neg), then x * scale = h0 + h1 as in split2_kernel.
-// Workgroup: 64 queries x 128 training points (8 k16 blocks); a wave instruction writes 2 KiB of contiguous output.
+// padding, never stored as fp32: a lane computes the eight values of one (query, k-half) and writes their two fp16 parts
+// as two 16-byte chunks of the layout of k5_direct_kernel (gpk_k5split.hip: chunk (q, k16 block kb, half h, part s) at
+// (((q / 32) * KB + kb) * 2 + s) * 64 + h * 32 + q % 32) - a separate fp32 panel (2.65 GB at the headline shape) and a
+// pass that splits it (2.65 GB read + 2.65 GB written) never exist.  Same arithmetic per entry as cross_t_kernel (exact
+// differences of the length-scale-divided coordinates, FMA accumulation, exp_neg), then x * scale = h0 + h1.
+// Workgroup: 64 queries x 128 training points (the staged points are reused 64 times); lane = h * 32 + q % 32 owns ONE
+// query and the k-half h of four consecutive k16 blocks; every wave instruction of the store writes 1 KiB of
+// contiguous output.
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 template <int DD>   // DD = D (query coordinates in registers; one instantiation per feature count)
 __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restrict__ Xq, long long M,
                                                            const float* __restrict__ X, long long N, int D, LsArr ls,
                                                            float sf2, float scale, u4_t* __restrict__ dst, long long Np) {
-  // 64 queries (four quads per wave, one after the other) x 128 training points per workgroup: the staged points are
-  // reused 64 times
   __shared__ __attribute__((aligned(16))) float xs[DD][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long j0 = (long long)blockIdx.x * 128, q0 = (long long)blockIdx.y * 64;
@@ -329,24 +329,16 @@ __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restri
     xs[d][i] = (d < D && gj < N) ? X[gj * D + d] / (float)ls.v[d] : 0.f;
   }
   __syncthreads();
-  const int qq = (lane >> 1) & 3, kb = lane >> 3, hh = lane & 1;
-  const int kbase = 16 * kb + 8 * hh;
-  // the four quads' coordinates up front (one round of loads in flight), divided by the length-scales as everywhere
-  float xqa[4][DD];
+  const int r = lane & 31, hh = lane >> 5;
+  // two query blocks of 32 per workgroup; a wave takes four of the eight k16 blocks of one of them
+  const long long qblk = (q0 >> 5) + (wave >> 1), q = qblk * 32 + r;
+  float xq[DD];
+#pragma unroll
+  for (int d = 0; d < DD; ++d) xq[d] = (q < M ? Xq[q * DD + d] : 0.f) / (float)ls.v[d];
+  const long long KB = Np >> 4;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const long long q = 4 * ((q0 >> 2) + 4 * wave + t) + qq;
-#pragma unroll
-    for (int d = 0; d < DD; ++d) xqa[t][d] = q < M ? Xq[q * DD + d] : 0.f;
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int d = 0; d < DD; ++d) xqa[t][d] = xqa[t][d] / (float)ls.v[d];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const long long quad = (q0 >> 2) + 4 * wave + t, q = 4 * quad + qq;
-    const float (&xq)[DD] = xqa[t];
+    const int kb = 4 * (wave & 1) + t, kbase = 16 * kb + 8 * hh;
     float d2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) d2[i] = 0.f;
@@ -367,10 +359,9 @@ __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restri
       p0[i] = h0;
       p1[i] = (_Float16)(x - (float)h0);
     }
-    // chunk index: (((q / 4) * (Np / 16) + k16 block) * 4 + q % 4) * 4 + half * 2 + part
-    u4_t* o = dst + (((quad * (Np >> 4) + (j0 >> 4) + kb) * 4 + qq) * 4 + hh * 2);
+    u4_t* o = dst + ((qblk * KB + (j0 >> 4) + kb) * 2) * 64 + lane;
     o[0] = __builtin_bit_cast(u4_t, p0);
-    o[1] = __builtin_bit_cast(u4_t, p1);
+    o[64] = __builtin_bit_cast(u4_t, p1);
   }
 }
 
@@ -644,6 +635,31 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int S
   for (int k = 0; k < S; ++k) s += partial[(long long)k * Mp + m];
   var[m] = fmax(kss - s, floor_);
 }
+// the same with the un-normalisation and the packing of a serving step's result folded in:
+// out[m] = [mean[m][0..P) | max(kss - sum_k partial[k][m], floor) * y_std[p]^2, p = 0..P)   (sklearn/_gpr.py:487-489)
+__global__ void colsum_finalize_packed_kernel(const double* __restrict__ partial, int S, long long Mp, long long M, double kss,
+                                              double floor_, const float* __restrict__ mean, int P, PArr ystd,
+                                              double recheck_below, unsigned* __restrict__ low_count,
+                                              double* __restrict__ out) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int k = 0; k < S; ++k) s += partial[(long long)k * Mp + m];
+  const double v = fmax(kss - s, floor_);
+  if (low_count && v < recheck_below) atomicAdd(low_count, 1u);      // (the fp32 serving gate: rows the caller recomputes)
+  double* o = out + m * 2 * P;
+  for (int p = 0; p < P; ++p) { o[p] = (double)mean[m * P + p]; o[P + p] = v * ystd.v[p] * ystd.v[p]; }
+}
+// [mean | var y_std^2] rows from a separate mean (M x P, fp32 or fp64) and variance (M, fp64)
+template <typename T>
+__global__ void pack_mean_var_kernel(const T* __restrict__ mean, const double* __restrict__ var, long long M, int P, PArr ystd,
+                                     double* __restrict__ out) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double* o = out + m * 2 * P;
+  const double v = var[m];
+  for (int p = 0; p < P; ++p) { o[p] = (double)mean[m * P + p]; o[P + p] = v * ystd.v[p] * ystd.v[p]; }
+}
 __global__ void var_finalize_kernel(const double* ss, long long M, double kss, double floor_, double* var) {
   const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -703,7 +719,7 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
   return GPK_OK;
 }
 
-// Kq (gpk_padded(M) x Np) in the gpk_split2 layout, from fp32 coordinates (internal: gpk_predict_var_inv_split2)
+// Kq (gpk_padded(M) x Np) in the fragment-order fp16 x 2 layout, from fp32 coordinates (internal: gpk_predict_var_inv_split2)
 int gpk_cross_split2(gpk_handle h, const float* Xq, int64_t M, const float* X, int64_t N, int D, const double* ls,
                      double sf2, double scale, void* dst) {
   GPK_REQUIRE(h, Xq && X && dst && M >= 1 && N >= 1 && D >= 1 && D <= DCH, "cross_split2: bad argument");
@@ -931,6 +947,31 @@ int gpk_colsum_finalize(gpk_handle h, const double* partial, int S, int64_t Mp, 
                         double* var) {
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, partial, S,
                      (long long)Mp, (long long)M, kss, floor_, var);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+int gpk_colsum_finalize_packed(gpk_handle h, const double* partial, int S, int64_t Mp, int64_t M, double kss, double floor_,
+                               const float* mean, int P, const double* y_std, double recheck_below, unsigned* low_count,
+                               double* out) {
+  PArr ys{};
+  for (int p = 0; p < P; ++p) ys.v[p] = y_std[p];
+  hipLaunchKernelGGL(colsum_finalize_packed_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, partial, S,
+                     (long long)Mp, (long long)M, kss, floor_, mean, P, ys, recheck_below, low_count, out);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+extern "C" int gpk_pack_mean_var(gpk_handle h, int dtype, const void* mean, const double* var, int64_t M, int P,
+                                 const double* y_std, double* out) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, mean && var && y_std && out && M >= 1 && P >= 1 && P <= GPK_MAX_P, "pack_mean_var: bad argument");
+  GPK_REQUIRE(h, dtype == GPK_F32 || dtype == GPK_F64, "pack_mean_var: bad dtype");
+  PArr ys{};
+  for (int p = 0; p < P; ++p) ys.v[p] = y_std[p];
+  const dim3 grid((unsigned)((M + 255) / 256));
+  if (dtype == GPK_F32)
+    hipLaunchKernelGGL(pack_mean_var_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)mean, var, (long long)M, P, ys, out);
+  else
+    hipLaunchKernelGGL(pack_mean_var_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)mean, var, (long long)M, P, ys, out);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }

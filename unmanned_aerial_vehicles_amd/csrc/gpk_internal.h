@@ -41,10 +41,9 @@ struct gpk_context {
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
   int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
-  int k5_split_form = 1;     // bf16 x 3 variance launch: 1 = 32x32x16 MFMAs, register-staged; 2 = 16x16x32 fused-term MFMAs,
-                             // LDS filled by DMA (GPK_K5_SPLIT_FORM)
-  int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = 512 x 128 tiles (128 x 64 per wave) when >= 512 of them, else
-                             // 64 x 64 per wave; 1 = always 64 x 64 per wave; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
+  int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
+                             // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
+  int k5_direct_sync = 24;   // k5_direct_kernel: workgroup barrier every this many k-tiles (GPK_K5_DIRECT_SYNC; 0: never)
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // gpk_timing: HIP-event brackets around the dominant launches (K5 variance GEMM, K1 Gram kernel), a ring of pairs
@@ -175,10 +174,13 @@ int gpk_small_predict(gpk_handle h, int B, const double* const* X, const double*
                       const double* const* W, int64_t Np, int64_t ldw, const double* kss, double floor_,
                       const double* Xq, int64_t M, double* work, double* mean_out, double* var_out);
 
-// K* straight into the fp16 x 2 split layout (gpk_gram.hip); D <= 16
+// K* straight into the fragment-order fp16 x 2 split layout (gpk_gram.hip); D <= 16
 int gpk_cross_split2(gpk_handle h, const float* Xq, int64_t M, const float* X, int64_t N, int D, const double* ls,
                      double sf2, double scale, void* dst);
 int gpk_var_finalize(gpk_handle h, const double* ss, int64_t M, double kss, double floor_, double* var);
 int gpk_colsum_reduce(gpk_handle h, const double* partial, int S, int64_t Mp, double* out);
 int gpk_colsum_finalize(gpk_handle h, const double* partial, int S, int64_t Mp, int64_t M, double kss, double floor_,
                         double* var);   // both of the above in one launch (entries M..Mp of var are left alone)
+int gpk_colsum_finalize_packed(gpk_handle h, const double* partial, int S, int64_t Mp, int64_t M, double kss, double floor_,
+                               const float* mean, int P, const double* y_std, double recheck_below, unsigned* low_count,
+                               double* out);   // + [mean | var y_std^2] rows

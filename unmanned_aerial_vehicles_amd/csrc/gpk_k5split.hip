@@ -1,22 +1,24 @@
-// K5 on the bf16 matrix pipe at fp32 accuracy: V = W Kq^T with both fp32 operands split EXACTLY into three bf16
-// parts (x = x0 + x1 + x2, 8 significant bits each, by truncation; gpk_split3) and every 32 x 32 x 16 block
-// product formed by six v_mfma_f32_32x32x16_bf16 (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0: bf16 x bf16 products
-// are exact, accumulation is fp32, the dropped cross terms are below 2^-24 of |a||b|, i.e. below the rounding of
-// an fp32 FMA).  The fp32 MFMA runs at the vector rate (157 TF); the bf16 pipe is 16x faster, so six instructions
-// per fp32-equivalent product raise the ceiling of this launch by 16/6 = 2.7x.
+// K5 on the 16-bit matrix pipe at fp32 accuracy: V = W Kq^T with both fp32 operands split into 16-bit parts, the tile
+// reduced to per-column sums of squares (fp64) in the epilogue instead of being stored.  Two forms:
 //
-// Operand layout (gpk_split3): 16-byte chunks [row / 4][k16 block][row % 4][half h][part s] - the eight bf16 of
-// part s for k = 16 kb + 8 h .. + 7 - so that one k-tile of 16 of four consecutive rows is 384 contiguous bytes =
-// three whole cache lines (consecutive lanes fetch consecutive chunks, a wave instruction touches 8 lines; with
+//  * fp16 x 2 (k5_direct_kernel; the fp32 serving default): x s = h0 + h1, two fp16 parts rounded to nearest (s: one power
+//    of two per 128-row block), block products a1 b0 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16, fp32 accumulation.  The
+//    operands are stored in "fragment order" and go from L2 straight into registers: no LDS, no barriers.
+//  * bf16 x 3 (k5_split_kernel): x = x0 + x1 + x2 EXACTLY, three bf16 parts, six products per block (a0 b0, a0 b1, a1 b0,
+//    a1 b1, a0 b2, a2 b0: bf16 x bf16 products are exact, the dropped cross terms are below 2^-24 of |a||b|); twice the
+//    matrix-pipe work of the first form.  Register-staged LDS pipeline on 128 x 128 or 256 x 128 tiles.
+//
+// The fp32 MFMA runs at the vector rate (157 TF); the 16-bit pipe is 16x faster, so three (six) instructions per
+// fp32-equivalent product raise the ceiling of this launch by 5.3x (2.7x).
+//
+// Operand layout of the bf16 x 3 form (gpk_split3): 16-byte chunks [row / 4][k16 block][row % 4][half h][part s] - the
+// eight bf16 of part s for k = 16 kb + 8 h .. + 7 - so that one k-tile of 16 of four consecutive rows is 384 contiguous
+// bytes = three whole cache lines (consecutive lanes fetch consecutive chunks, a wave instruction touches 8 lines; with
 // plain row-major 96-byte pieces it touched 11-22 partial lines, and variants that fetched 16- or 32-byte pieces per
-// row were 20-45 % slower: the fetch granularity is what this kernel is most sensitive to) and a lane's
-// MFMA fragment (row r = lane & 31, k half h = lane >> 5) is one ds_read_b128 per part.  LDS rows are padded to
-// 112 bytes (28 dwords = 4 x odd: conflict-free b128 reads over 8 consecutive rows).
-//
-// The kernel is the K5 launch only: 128 x 128 tiles, 4 waves of 64 x 64 (2 x 2 blocks of 32 x 32), k-tiles of 16,
-// the same register-staged pipeline, scalar-based buffer loads, band-linear super-tiles in serpentine XCD order,
-// heavy-first rows and lockstep k-ranges as gemm_kernel (gpk_gemm.hip), and its epilogue reduces the tile to
-// per-column sums of squares (fp64) instead of storing it.
+// row were 20-45 % slower) and a lane's MFMA fragment (row r = lane & 31, k half h = lane >> 5) is one ds_read_b128 per
+// part.  LDS rows are padded to 112 bytes (28 dwords = 4 x odd: conflict-free b128 reads over 8 consecutive rows).
+// Both kernels share the tile mapping of gemm_kernel (gpk_gemm.hip): band-linear super-tiles in serpentine XCD order,
+// heavy-first rows and lockstep k-ranges.
 //
 // Replaces the same reference lines as gpk_predict_var_inv (sklearn/gaussian_process/_gpr.py:454-485).
 #include <cmath>
@@ -31,21 +33,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 template <int V> struct IntC { static constexpr int value = V; };
 
 constexpr int ROWB = 384;      // bytes of one k-tile (16 k) of a quad of rows: 4 rows x 2 halves x 3 parts x 16 B
-// the same two constants for NPART parts per value (3: bf16 x 3, exact; 2: fp16 x 2, 22 significant bits)
-template <int NPART> constexpr int rowb_v = 4 * 2 * NPART * 16;
-// LDS row of a k-tile: the row's 2 NPART chunks of 16 bytes plus 16 bytes of padding (112 / 80 bytes = 4 x odd dwords:
-// conflict-free ds_read_b128).  The padded 80-byte row of the fp16 x 2 split makes every ds_write_b128 2-way (banks
-// (a/4) % 32, 8 contiguous lanes = rows r and r+1, which overlap in 4 of the 32 store banks: SQ_LDS_BANK_CONFLICT = 31 % of
-// SQ_LDS_IDX_ACTIVE).  The swizzled form (SW = 2) has neither: 64-byte rows, no padding, chunk c of row r stored at
-// position c ^ ((r >> 2) & 3) - a ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: four row quads
-// whose (r >> 2) & 3 all differ) lands on 16 different 16-byte slots of the 256-byte bank row, and 8 contiguous lanes of a
-// store cover 128 contiguous bytes.  Measured on one box (profiles/r02_k5_forms_ab.log): zero conflicts and 2.4 % fewer
-// clock cycles, but the chip then holds 1.49 instead of 1.60 GHz under the 256 x 128-tile kernel (+5 % time); under the
-// 512 x 128-tile kernel it is 0.8 % faster.  So the swizzle is used with the large tile only.
-template <int SW, int NPART> constexpr int lrow_v = SW == 2 ? 64 : 2 * NPART * 16 + 16;
-template <bool SWZ> __device__ __forceinline__ int lds_chunk(int row, int chunk) {
-  return SWZ ? (chunk ^ ((row >> 2) & 3)) : chunk;
-}
+constexpr int LROW = 112;      // LDS row of a k-tile: the row's 6 chunks of 16 bytes plus 16 bytes of padding (28 dwords = 4 x odd)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // bf16 part of a finite fp32 value, rounded to nearest even (as bits in the upper half of a dword)
@@ -91,44 +79,6 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
   d[0] = f[0]; d[1] = f[1]; d[2] = f[2];
 }
 
-// ---- fp16 x 2 split (the optional fast form): x * scale = h0 + h1 + r with h0, h1 fp16 (rounded to nearest), |r| <= 2^-22 |x|
-// for values whose second part is a normal fp16 number (|x * scale| >= 2^-3) and <= 2^-25 * 2^15 / scale absolutely
-// below that; `scale` (a power of two chosen by the caller so that max |x * scale| <= 2^15) puts the operand's
-// largest entries at the top of fp16's range.  Chunk order [row / 4][k16 block][row % 4][half][part]: 64 bytes per row
-// and k-tile, 256 contiguous bytes per quad of rows.
-__global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ src, long long rows, long long cols,
-                                                     long long ld, float scale, V16* __restrict__ dst) {
-  const long long hc = cols / 8;
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= rows * hc) return;
-  const long long row = e / hc, hb = e - row * hc;
-  const float4* s4 = reinterpret_cast<const float4*>(src + row * ld + hb * 8);
-  const float4 lo = s4[0], hi = s4[1];
-  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  f16x8 p0, p1;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float x = v[j] * scale;
-    const _Float16 h0 = (_Float16)x;
-    p0[j] = h0;
-    p1[j] = (_Float16)(x - (float)h0);
-  }
-  V16* d = dst + (((row >> 2) * (hc >> 1) + (hb >> 1)) * 4 + (row & 3)) * 4 + (hb & 1) * 2;
-  d[0] = __builtin_bit_cast(V16, p0);
-  d[1] = __builtin_bit_cast(V16, p1);
-}
-
-// max |A_ij| over the lower triangle (j <= i) of a square fp32 matrix: one row per workgroup, one atomic per row
-// (the bit pattern of a non-negative float orders like the value)
-__global__ __launch_bounds__(256) void tril_absmax_kernel(const float* __restrict__ A, long long n, long long lda,
-                                                          unsigned* __restrict__ out) {
-  const long long i = blockIdx.x;
-  float m = 0.f;
-  for (long long j = threadIdx.x; j <= i; j += 256) m = fmaxf(m, fabsf(A[i * lda + j]));
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
-}
-
 struct SParams {
   const char* A;        // W, split layout, Np rows
   const char* B;        // Kq, split layout, Mp rows
@@ -136,41 +86,22 @@ struct SParams {
   long long rsa, rsb;   // bytes between consecutive quads of rows (Np * 24)
   long long Mp;
   int ntm, ntn, nst;
-  float alpha;
 };
 
-template <int NP>
-__device__ __forceinline__ void load3(const char* __restrict__ ubase, const unsigned (&voff)[NP], V16 (&r)[NP]) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-  for (int p = 0; p < NP; ++p) r[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], 0, 0);
-}
-
-// WR wave rows x 2 wave columns of 64 x 64 per workgroup: WR = 2 -> 128 x 128 tile, 4 waves, 2 workgroups per CU;
-// WR = 4 -> 256 x 128 tile, 8 waves, 1 workgroup per CU (25 % less operand staging per MFMA)
-// NPART = 3: bf16 parts, six products per block (exact); NPART = 2: fp16 parts, three products (a1 b0, a0 b1, a0 b0)
-// AB: 32-row blocks per wave.  2: 64 x 64 per wave.  4 (with WR = 4): 128 x 64 per wave, 512 x 128 tiles, one
-// workgroup per CU at 2 waves per SIMD (256 VGPRs) - 17 % fewer operand bytes from L2 per product and 0.5 instead of
-// 0.67 fragment reads per MFMA: the launch is limited by the clock the chip holds under this load, and less data
-// movement per product is what raises it (9 % faster at the headline shape).  Needs >= 512 tiles to fill the chip.
-template <int WR, int NPART = 3, int AB = 2>
-__global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SParams p) {
-  constexpr bool SWZ = AB == 4;                                   // swizzled 64-byte LDS rows (see lrow_v)
-  constexpr int LROW = lrow_v<SWZ ? 2 : 3, NPART>, ROWB = rowb_v<NPART>, CPR = 2 * NPART;      // (shadow the bf16 x 3 constants)
-  constexpr int TMR = 32 * AB * WR;                                // tile rows
+// WR wave rows x 2 wave columns of 64 x 64 (2 x 2 blocks of 32 x 32) per workgroup: WR = 2 -> 128 x 128 tile, 4 waves,
+// 2 workgroups per CU; WR = 4 -> 256 x 128 tile, 8 waves, 1 workgroup per CU (25 % less operand staging per MFMA)
+template <int WR>
+__global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
+  constexpr int TMR = 64 * WR;                                     // tile rows
   constexpr int SSZ = (TMR + 128) * LROW;                          // one LDS stage: [A k-tile | B k-tile]
   constexpr int BOFF = TMR * LROW;                                 // B inside a stage
-  // byte offsets of the A / B k-tile of LDS buffer `buf`.  AB = 4: [B0 | B1 | A0 | A1], so that every fragment read is
-  // within 64 KiB (the ds offset field) of one base register per operand and swizzle variant; else [A0 | B0 | A1 | B1].
-  auto AO = [](int buf) constexpr { return AB == 4 ? 2 * 128 * LROW + buf * TMR * LROW : buf * SSZ; };
-  auto BO = [](int buf) constexpr { return AB == 4 ? buf * 128 * LROW : buf * SSZ + BOFF; };
   __shared__ __attribute__((aligned(16))) char lds[2 * SSZ];
-  constexpr int NT = WR * 128, NCH = (TMR + 128) * CPR, NQ = (NCH + NT - 1) / NT;   // threads, chunks
+  constexpr int NT = WR * 128, NCH = (TMR + 128) * 6, NQ = (NCH + NT - 1) / NT;   // threads, 16-byte chunks per k-tile
   constexpr int GSZ = WR == 2 ? 64 : 32;                           // resident workgroups per XCD = tiles per group
   constexpr int BH = 1024 / TMR;                                   // band height in tile rows (1024 matrix rows)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int row_w = wm * 32 * AB, col_w = wn * 64;
+  const int row_w = wm * 64, col_w = wn * 64;
 
   // ---- tile mapping: bands of 1024 rows walked column by column in groups of GSZ tiles, serpentine over XCDs
   const int ntm = p.ntm * 128 / TMR;                               // tile rows of this configuration
@@ -179,16 +110,15 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
   if (st >= p.nst) return;
   const int per = BH * p.ntn, nfull = ntm / BH, hlast = ntm - nfull * BH, total = ntm * p.ntn;
-  auto place = [&](int t, int& row, int& col, int& band) {
-    band = min(t / per, nfull);
-    const int idx = t - band * per, hh = band < nfull ? BH : hlast;
-    col = idx / hh;
-    row = band * BH + (idx - col * hh);
-  };
   const int t = st * GSZ + slot;
   if (t >= total) return;
-  int tm, tn, band;
-  place(t, tm, tn, band);
+  int tm, tn;
+  {
+    const int band = min(t / per, nfull);
+    const int idx = t - band * per, hh = band < nfull ? BH : hlast;
+    tn = idx / hh;
+    tm = band * BH + (idx - tn * hh);
+  }
   // heavy first: row r of the enumeration is tile row ntm-1-r (its k-range is (row + 1) * TMR: longest first);
   // every tile of the group runs to the end of the group's longest row, the one enumerated first (W is zero
   // beyond a row's own range for 16 tiles of 128; a group spans at most two bands = 2048 rows)
@@ -200,9 +130,9 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   const int nkt = (rhi + 1) * (TMR / 16);        // k-tiles of 16
 
   const int row0 = tm * TMR, col0 = tn * 128;
-  f16v acc[AB][2];
+  f16v acc[2][2];
 #pragma unroll
-  for (int a = 0; a < AB; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -216,42 +146,19 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   for (int q = 0; q < NQ; ++q) {
     const int g = tid + NT * q;
     live[q] = __builtin_amdgcn_readfirstlane(g < NCH ? 1 : 0) != 0;
-    isb[q] = __builtin_amdgcn_readfirstlane(g >= TMR * CPR ? 1 : 0) != 0;
-    const int c = live[q] ? (isb[q] ? g - TMR * CPR : g) : 0, row = c / CPR, w = c - row * CPR;
-    goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * CPR + w) * 16);     // rsa: bytes between row quads
-    lofs[q] = (isb[q] ? BOFF : 0) + row * LROW + lds_chunk<SWZ>(row, w) * 16;
+    isb[q] = __builtin_amdgcn_readfirstlane(g >= TMR * 6 ? 1 : 0) != 0;
+    const int c = live[q] ? (isb[q] ? g - TMR * 6 : g) : 0, row = c / 6, w = c - row * 6;
+    goff[q] = (unsigned)((long long)(row >> 2) * p.rsa + ((row & 3) * 6 + w) * 16);     // rsa: bytes between row quads
+    lofs[q] = (isb[q] ? BOFF : 0) + row * LROW + w * 16;
   }
-  // fp16 x 2 (four chunks per row, NT a multiple of four, the A / B boundary on a multiple of NT): chunk q of a thread is
-  // its chunk 0 moved down NT / 4 rows per q - one vector offset plus a scalar step per q for the global address, one
-  // LDS offset plus constants for the store (NQ - 1 fewer address registers of each kind)
-  constexpr bool AFF = NPART == 2;
-  constexpr int QA = TMR * CPR / NT, QROWS = NT / CPR;
-  static_assert(!AFF || ((TMR * CPR) % NT == 0 && NCH % NT == 0 && NT % CPR == 0), "affine chunk addressing");
-  const int gstep = (int)((QROWS / 4) * p.rsa);                     // bytes between a thread's consecutive chunks (rsa == rsb)
   const char* ua = p.A + (long long)(row0 >> 2) * p.rsa;
   const char* ub = p.B + (long long)(col0 >> 2) * p.rsb;
-  // Register ring of RING k-tiles in flight: the fetch of k-tile kt+1+RING is issued when k-tile kt+1 leaves its
-  // ring slot for LDS.  The loop is unrolled by 4: slot and LDS buffer indices are constants.
-#ifndef GPK_K5S_SCHED
-#define GPK_K5S_SCHED 1
-#endif
-#ifndef GPK_K5S_RING
-#define GPK_K5S_RING 2
-#endif
-  constexpr int RING = GPK_K5S_RING;
-  V16 rr[RING][NQ];
+  // Register ring of two k-tiles in flight: the fetch of k-tile kt+4 is issued when k-tile kt+2 leaves its ring slot
+  // for LDS.  The loop is unrolled by 4: slot and LDS buffer indices are constants.
+  V16 rr[2][NQ];
   auto fetch = [&](int tile, auto slotc) {
     constexpr int sl = decltype(slotc)::value;
     const long long ko = (long long)min(tile, nkt - 1) * ROWB;
-    if constexpr (AFF) {
-      const __amdgpu_buffer_rsrc_t rsa_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ua + ko), 0, 0x7fffffff, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ub + ko), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        rr[sl][q] = q < QA ? __builtin_amdgcn_raw_buffer_load_b128(rsa_, goff[0], q * gstep, 0)
-                           : __builtin_amdgcn_raw_buffer_load_b128(rsb_, goff[0], (q - QA) * gstep, 0);
-      return;
-    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       if (NCH % NT != 0 && !live[q]) continue;      // (only the last chunk of the 256-row configuration can be absent)
@@ -262,69 +169,46 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   };
   auto stage = [&](auto bufc, auto slotc) {
     constexpr int sl = decltype(slotc)::value, bi = decltype(bufc)::value;
-    if constexpr (AFF) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        *reinterpret_cast<V16*>(lds + lofs[0] + (q < QA ? AO(bi) + q * QROWS * LROW : BO(bi) + (q - QA) * QROWS * LROW)) = rr[sl][q];
-      return;
-    }
-    static_assert(AFF || AB != 4, "the [B | A] buffer order is used with affine chunk addressing only");
     char* buf = lds + bi * SSZ;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (NCH % NT == 0 || live[q]) *reinterpret_cast<V16*>(buf + lofs[q]) = rr[sl][q];
   };
-#ifndef GPK_K5S_FPRE
-#define GPK_K5S_FPRE 1
-#endif
   const int fr = lane & 31, fh = lane >> 5;
-  auto mfmas = [&](const bf16x8 (&af)[AB][NPART], const bf16x8 (&bf)[2][NPART]) {
+  auto mfmas = [&](const bf16x8 (&af)[2][3], const bf16x8 (&bf)[2][3]) {
     // smallest terms first
 #pragma unroll
-    for (int a = 0; a < AB; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         f16v c = acc[a][b];
-        if constexpr (NPART == 2) {
-          const f16x8 a0 = __builtin_bit_cast(f16x8, af[a][0]), a1 = __builtin_bit_cast(f16x8, af[a][1]);
-          const f16x8 b0 = __builtin_bit_cast(f16x8, bf[b][0]), b1 = __builtin_bit_cast(f16x8, bf[b][1]);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
-        } else {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);
-        }
         acc[a][b] = c;
       }
   };
-  auto frags = [&](auto bufc, bf16x8 (&af)[AB][NPART], bf16x8 (&bf)[2][NPART]) {
+  auto frags = [&](auto bufc, bf16x8 (&af)[2][3], bf16x8 (&bf)[2][3]) {
     constexpr int bi = decltype(bufc)::value;
 #pragma unroll
-    for (int a = 0; a < AB; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int s = 0; s < NPART; ++s)
-        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + AO(bi) + (row_w + 32 * a + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + s) * 16));
+      for (int s = 0; s < 3; ++s)
+        af[a][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + bi * SSZ + (row_w + 32 * a + fr) * LROW + (fh * 3 + s) * 16));
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int s = 0; s < NPART; ++s)
-        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + BO(bi) + (col_w + 32 * b + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + s) * 16));
+      for (int s = 0; s < 3; ++s)
+        bf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + bi * SSZ + BOFF + (col_w + 32 * b + fr) * LROW + (fh * 3 + s) * 16));
   };
-#if GPK_K5S_FPRE
   // Fragments one k-tile ahead: while the MFMAs of k-tile kt run out of registers F[kt & 1], the fragments of k-tile
   // kt+1 are read from LDS buffer (kt+1) & 1 into F[(kt+1) & 1] and k-tile kt+2 is written into LDS buffer kt & 1
   // (its previous content, k-tile kt, was read during iteration kt-1; the barrier at the end of each iteration
   // separates the two).  No MFMA waits for LDS.
-  static_assert(RING == 2, "the fragment-prefetch pipeline is written for a ring of two k-tiles");
-  // (AB = 4: the A fragments are single-buffered - a row block's fragments of the next k-tile replace the ones its
-  // MFMAs have just used - which keeps the 128 x 64 wave tile inside 256 registers)
-  constexpr int NFA = AB == 4 ? 1 : 2;
-  bf16x8 FA[NFA][AB][NPART], FB[2][2][NPART];
+  bf16x8 FA[2][2][3], FB[2][2][3];
   fetch(0, IntC<0>{});
   stage(IntC<0>{}, IntC<0>{});
   fetch(1, IntC<1>{});
@@ -334,81 +218,15 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   __syncthreads();
   frags(IntC<0>{}, FA[0], FB[0]);
   __syncthreads();
-  // (AB = 4: the last row block's A fragments ARE double-buffered, so that an iteration can end with that block's MFMAs
-  // and its LDS reads are long complete at the barrier)
-  bf16x8 FA3[2][NPART];
-  if constexpr (AB == 4) {
-#pragma unroll
-    for (int sp = 0; sp < NPART; ++sp) FA3[0][sp] = FA[0][AB - 1][sp];
-  }
   auto body = [&](int kt, auto ksc) {
-    constexpr int KS = decltype(ksc)::value, cur = KS & 1;
-    if constexpr (AB == 4) {
-      // The 128 x 64 wave tile, issue order written out and fenced (sched_barrier: nothing moves across): MFMAs from the
-      // first cycle after the barrier (their operands are in registers); k-tile kt+2 goes from the ring registers to LDS
-      // buffer `cur` one store per three MFMAs, each global load of k-tile kt+4 behind the store that frees its
-      // registers; a row block's A fragments of k-tile kt+1 are read behind that block's MFMAs, the B fragments and the
-      // last block's (double-buffered) A fragments before the last twelve MFMAs, which end the iteration.
-      static_assert(AB != 4 || (NPART == 2 && NQ == 5 && AFF), "the 128 x 64 wave tile is written for the fp16 x 2 split");
-      const long long ko = (long long)min(kt + 4, nkt - 1) * ROWB;
-      const __amdgpu_buffer_rsrc_t rsa_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ua + ko), 0, 0x7fffffff, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ub + ko), 0, 0x7fffffff, 0x00020000);
-      auto st = [&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        *reinterpret_cast<V16*>(lds + lofs[0] + (q < QA ? AO(cur) + q * QROWS * LROW : BO(cur) + (q - QA) * QROWS * LROW)) = rr[cur][q];
-      };
-      auto ld = [&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        rr[cur][q] = q < QA ? __builtin_amdgcn_raw_buffer_load_b128(rsa_, goff[0], q * gstep, 0)
-                            : __builtin_amdgcn_raw_buffer_load_b128(rsb_, goff[0], (q - QA) * gstep, 0);
-      };
-      auto rdA = [&](int a, bf16x8 (&dst)[NPART]) {
-#pragma unroll
-        for (int sp = 0; sp < NPART; ++sp)
-          dst[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + AO(cur ^ 1) + (row_w + 32 * a + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + sp) * 16));
-      };
-      auto rdB = [&](int b_, bf16x8 (&dst)[NPART]) {
-#pragma unroll
-        for (int sp = 0; sp < NPART; ++sp)
-          dst[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(lds + BO(cur ^ 1) + (col_w + 32 * b_ + fr) * LROW + lds_chunk<SWZ>(fr, fh * NPART + sp) * 16));
-      };
-      auto mm = [&](int a, int b, const bf16x8 (&fa)[NPART], const bf16x8 (&fb)[NPART]) {
-        const f16x8 a0 = __builtin_bit_cast(f16x8, fa[0]), a1 = __builtin_bit_cast(f16x8, fa[1]);
-        const f16x8 b0 = __builtin_bit_cast(f16x8, fb[0]), b1 = __builtin_bit_cast(f16x8, fb[1]);
-        f16v c = acc[a][b];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);       // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
-        acc[a][b] = c;
-      };
-      // column block 0 first (its B fragments are single-buffered: FB[0][0], reloaded once its four products are done),
-      // then column block 1 (FB[cur][1]; the row blocks' A fragments are reloaded behind their second product)
-#define GPK_FENCE() __builtin_amdgcn_sched_barrier(0)
-      mm(0, 0, FA[0][0], FB[0][0]); GPK_FENCE();
-      st(IntC<0>{}); GPK_FENCE();
-      mm(1, 0, FA[0][1], FB[0][0]); GPK_FENCE();
-      st(IntC<1>{}); GPK_FENCE();
-      mm(2, 0, FA[0][2], FB[0][0]); GPK_FENCE();
-      st(IntC<2>{}); GPK_FENCE();
-      mm(3, 0, FA3[cur], FB[0][0]); GPK_FENCE();
-      st(IntC<3>{}); rdB(0, FB[0][0]); GPK_FENCE();
-      mm(0, 1, FA[0][0], FB[cur][1]); GPK_FENCE();
-      st(IntC<4>{}); ld(IntC<0>{}); rdA(0, FA[0][0]); GPK_FENCE();
-      mm(1, 1, FA[0][1], FB[cur][1]); GPK_FENCE();
-      ld(IntC<1>{}); ld(IntC<2>{}); rdA(1, FA[0][1]); GPK_FENCE();
-      mm(2, 1, FA[0][2], FB[cur][1]); GPK_FENCE();
-      ld(IntC<3>{}); ld(IntC<4>{}); rdA(2, FA[0][2]); rdB(1, FB[cur ^ 1][1]); rdA(3, FA3[cur ^ 1]); GPK_FENCE();
-      mm(3, 1, FA3[cur], FB[cur][1]); GPK_FENCE();
-#undef GPK_FENCE
-      __syncthreads();
-      return;
-    }
+    constexpr int cur = decltype(ksc)::value & 1;
     stage(IntC<cur>{}, IntC<cur>{});            // k-tile kt+2 (ring slot (kt+2) % 2 = cur)
     fetch(kt + 4, IntC<cur>{});
-    frags(IntC<(cur ^ 1)>{}, FA[(cur ^ 1) % NFA], FB[cur ^ 1]);
-    mfmas(FA[cur % NFA], FB[cur]);
-#if GPK_K5S_SCHED
-    constexpr int NMF = (NPART == 3 ? 6 : 3) * AB * 2, NRD = NPART * (AB + 2);
+    frags(IntC<(cur ^ 1)>{}, FA[cur ^ 1], FB[cur ^ 1]);
+    mfmas(FA[cur], FB[cur]);
+    // issue order: the LDS stores of k-tile kt+2 first, then MFMAs with the fragment reads and the global loads spread
+    // evenly among them
+    constexpr int NMF = 24, NRD = 12;
     __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
 #pragma unroll
     for (int g = 0; g < NQ; ++g) {
@@ -416,48 +234,14 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
       __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NQ - 1) / NQ, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
-#endif
     __syncthreads();
   };
-#else
-  fetch(0, IntC<0>{});
-  stage(IntC<0>{}, IntC<0>{});
-  fetch(1, IntC<1 % RING>{});
-  if constexpr (RING >= 2) fetch(2, IntC<2 % RING>{});
-  if constexpr (RING >= 3) fetch(3, IntC<3 % RING>{});
-  if constexpr (RING >= 4) { fetch(4, IntC<0>{}); }
-  __syncthreads();
-  // iteration kt (kt % RING == KS): k-tile kt+1 goes from ring slot (KS+1) % RING to LDS buffer (kt+1) & 1, that
-  // slot is refilled with k-tile kt+1+RING, and k-tile kt is multiplied out of LDS buffer kt & 1
-  auto body = [&](int kt, auto ksc) {
-    constexpr int KS = decltype(ksc)::value, cur = KS & 1, sl = (KS + 1) % RING;
-    stage(IntC<(cur ^ 1)>{}, IntC<sl>{});
-    fetch(kt + 1 + RING, IntC<sl>{});
-    bf16x8 af[AB][NPART], bf[2][NPART];
-    frags(IntC<cur>{}, af, bf);
-    mfmas(af, bf);
-#if GPK_K5S_SCHED
-    // issue order: LDS writes of the next k-tile, all twelve fragment reads, then the MFMAs with the six
-    // buffer loads spread among them (the scheduler otherwise trickles the reads between MFMAs and waits five times)
-    __builtin_amdgcn_sched_group_barrier(0x200, NQ, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, NPART * (AB + 2), 0);
-#pragma unroll
-    for (int g = 0; g < NQ; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, ((NPART == 3 ? 6 : 3) * AB * 2 + NQ - 1) / NQ, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-#endif
-    __syncthreads();
-  };
-#endif
-  int kt = 0;
-  for (; kt + 3 < nkt; kt += 4) {
-    body(kt, IntC<0 % RING>{});
-    body(kt + 1, IntC<1 % RING>{});
-    body(kt + 2, IntC<2 % RING>{});
-    body(kt + 3, IntC<3 % RING>{});
+  for (int kt = 0; kt + 3 < nkt; kt += 4) {      // nkt is a multiple of 8 (k-ranges are whole 128-tiles): no remainder
+    body(kt, IntC<0>{});
+    body(kt + 1, IntC<1>{});
+    body(kt + 2, IntC<2>{});
+    body(kt + 3, IntC<3>{});
   }
-  // nkt is a multiple of 8 (k-ranges are whole 128-tiles): no remainder
 
   // ---- epilogue: per-column sums of squares of the tile (fp64), out[tile row][column]
   double* red = reinterpret_cast<double*>(lds);      // [WR][128]; the k-loop ended with a barrier
@@ -465,9 +249,9 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   for (int b = 0; b < 2; ++b) {
     float s = 0.f;
 #pragma unroll
-    for (int a = 0; a < AB; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const float v = p.alpha * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
+      for (int i = 0; i < 16; ++i) { const float v = acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) red[wm * 128 + col_w + 32 * b + lane] = (double)s;
   }
@@ -480,39 +264,41 @@ __global__ __launch_bounds__(WR * 128, AB == 4 ? 1 : 2) void k5_split_kernel(SPa
   }
 }
 
+// ---- third form of the fp16 x 2 launch: operands straight from L2 into MFMA fragments, no LDS ------------------------
+// "Fragment order" of a split operand (layout 1): the 16-byte chunk (row, k16 block kb, half h, part s) lives at chunk
+// index (((row / 32) * KB + kb) * 2 + s) * 64 + h * 32 + row % 32 (KB = cols / 16): the 64 chunks of one
+// (32-row block, k16 block, part) - exactly one v_mfma_f32_32x32x16_f16 operand, lane = h * 32 + row % 32 - are 1 KiB
+// of contiguous memory, so a fragment is ONE fully coalesced buffer_load_dwordx4 per wave (eight whole 128-byte lines),
+// and a 32-row block is (cols / 16) * 2 KiB of contiguous memory.
+// The launch: tiles of (128 AB) x 128, four waves, one per SIMD with the whole 512-register file; wave w owns rows
+// 32 AB w .. of the tile and ALL 128 columns (AB x 4 accumulator blocks of 32 x 32: 256 registers at AB = 4).  A row
+// block of W is used by one wave only, so nothing is gained by staging it in LDS: each wave loads its own A fragments
+// straight into registers (they come from L2 exactly once per workgroup, as before) and the four waves' identical B
+// (K*) fragment loads meet in the CU's vector L1.  Per k16 step and workgroup: 40 KiB from L2 as before, but no LDS
+// writes (40 KiB before) and no LDS reads (96 KiB before), no barriers, half the fragment bytes per MFMA (0.33
+// fragment loads per MFMA against 0.5).  The launch is bound by the clock the chip holds under this load
+// (profiles/r02_pmc_mfma_k5_fp16x2.txt: MFMA busy 0.89 at 1.39 GHz): less data movement per product is what raises it.
+// A ring of three k-tiles of fragments (3 x 64 registers) keeps two k-tiles in flight; a fragment's registers are
+// refilled (k-tile kt + 3) right behind the last MFMA that reads them.
+struct DParams {
+  const char* A;        // W, fragment order, Np rows
+  const char* B;        // K*, fragment order, Mp rows
+  double* out;          // [Np / (128 AB)][Mp] partial column sums of squares
+  const float* wscale;  // the power-of-two scale of each 128-row block of W (gpk_split2_rows)
+  long long rba, rbb;   // bytes of one 32-row block (Np * 128)
+  long long Mp;
+  float kscale;         // the scale of K*
+  int ntm, ntn, nst;    // 128-row tile rows, 128-column tile columns, super-tiles
+  int sync_every;       // a workgroup barrier every this many k-tiles keeps the four waves' B loads together in L1 (0: never)
+};
 
-// ---- second form of the same launch: 16 x 16 x 32 MFMAs, two product terms per instruction, LDS filled by DMA --------
-// The six products of a block pair up into three v_mfma_f32_16x16x32_bf16: the instruction's k = 32 is used as
-// [k16 of one part | k16 of another part], with the B operand carrying the complementary parts -
-//     (a0 b1 + a1 b0):  A = [a0 | a1], B = [b1 | b0]      (a0 b2 + a2 b0):  A = [a0 | a2], B = [b2 | b0]
-//     (a0 b0 + a1 b1):  A = [a0 | a1], B = [b0 | b1]
-// (lane l of a fragment holds row l & 15 and the eight k of k-group l >> 4: groups 0, 1 = the two halves of the first
-// part's k16, groups 2, 3 = those of the second part).  Same exact products, same fp32 accumulation, smallest terms
-// first; 3 x 16 cycles per 16 x 16 block and k16 = the 6 x 32 cycles per 32 x 32 block of the first form, but the
-// 16 x 16 x 32 shape holds a higher clock under this load (MI355X_MICROARCH.md, DVFS item 7).  Two A fragment
-// types and three B types per block: 20 ds_read_b128 per wave and k-tile (64 x 64 per wave) instead of 12.
-// With 96-byte LDS rows in the global chunk order ([row][half][part]) every one of those reads is conflict-free
-// (checked exhaustively over the four lane groups of ds_read_b128), so the LDS image of a k-tile IS the global
-// image of its row quads: the stage is filled by buffer_load_dwordx4 ... lds (1 KiB per wave instruction, no
-// registers, no ds_write), 36 of them per 256 x 128 tile and k-tile, into a ring of four 36 KiB stages with three
-// k-tiles in flight across the one barrier per k-tile.
-constexpr int V2_TM = 256, V2_TN = 128;
-constexpr int V2_STAGE = (V2_TM + V2_TN) * 96;      // 36864 bytes: [A k-tile | B k-tile]
-constexpr int V2_BOFF = V2_TM * 96;
-constexpr int V2_NSTG = 4;
-// (36 wave instructions of 1 KiB per stage: 24 of A, 12 of B)
-
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-__global__ __launch_bounds__(512, 2) void k5_split16_kernel(SParams p) {
-  __shared__ __attribute__((aligned(1024))) char lds[V2_NSTG * V2_STAGE];
-  constexpr int GSZ = 32, BH = 4;
+template <int AB>
+__global__ __launch_bounds__(256, 1) void k5_direct_kernel(DParams p) {
+  constexpr int TMR = 128 * AB, GSZ = 32, BH = 1024 / TMR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- tile mapping (as k5_split_kernel<4>): bands of 1024 rows, groups of 32 tiles, serpentine over XCDs, heavy first
-  const int ntm = p.ntm / 2;
+  // ---- tile mapping (as k5_split_kernel): bands of 1024 rows walked column by column in groups of 32 tiles, serpentine
+  // over the XCDs, heavy rows first, lockstep k-ranges inside a group
+  const int ntm = p.ntm * 128 / TMR;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int grp = j / GSZ, slot = j - grp * GSZ;
   const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
@@ -530,150 +316,142 @@ __global__ __launch_bounds__(512, 2) void k5_split16_kernel(SParams p) {
   const int band0 = min(st * GSZ / per, nfull), band1 = min(min(st * GSZ + GSZ - 1, total - 1) / per, nfull);
   tm = ntm - 1 - tm;
   const int rhi = (band1 - band0 <= 1) ? ntm - 1 - band0 * BH : tm;
-  const int nkt = (rhi + 1) * (V2_TM / 16);        // k-tiles of 16: at least 16
-  const int row0 = tm * V2_TM, col0 = tn * V2_TN;
+  const int nkt = (rhi + 1) * (TMR / 16);          // k-tiles of 16 (a multiple of 8)
+  const int row0 = tm * TMR, col0 = tn * 128;
 
-  // ---- DMA plan: wave instruction i = wave + 8 q (q = 0 .. 4) of the stage copies 64 consecutive 16-byte chunks;
-  // chunk c of an operand's k-tile lives at quad (c / 24) * rs + (c % 24) * 16 in global memory and at c * 16 in LDS
-  unsigned dvoff[5];
+  f16v acc[AB][4];
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const int i = wave + 8 * q;                                   // wave-uniform
-    const int c = ((i < 24 ? i : i - 24) * 64 + lane);
-    const int quad = c / 24, within = c - quad * 24;
-    dvoff[q] = (unsigned)((long long)quad * (i < 24 ? p.rsa : p.rsb) + within * 16);
-  }
-  // (instructions 32 .. 35 belong to waves 0 .. 3; waves 4 .. 7 repeat them - same source, same destination, same
-  // bytes - so that every wave issues five per k-tile and the loop needs no branch: q = 4 maps wave w to i = 32 + (w & 3))
-  {
-    const int i = 32 + (wave & 3);
-    const int c = (i - 24) * 64 + lane;
-    const int quad = c / 24, within = c - quad * 24;
-    dvoff[4] = (unsigned)((long long)quad * p.rsb + within * 16);
-  }
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(p.A + (long long)(row0 >> 2) * p.rsa), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(p.B + (long long)(col0 >> 2) * p.rsb), 0, 0x7fffffff, 0x00020000);
-  // k-tiles beyond the tile's range are clamped to the last one: a redundant copy into a stage nobody reads any more
-  // keeps the loop free of branches and the vmcnt bookkeeping uniform (five DMAs per wave and k-tile, always)
-  auto dma = [&](int kt) {
-    char* stg = lds + (kt & (V2_NSTG - 1)) * V2_STAGE;
-    const int so = min(kt, nkt - 1) * ROWB;                       // k-tile kt of every quad: + 384 bytes per k-tile
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stg + wave * 1024), 16, dvoff[0], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stg + 8192 + wave * 1024), 16, dvoff[1], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(stg + 16384 + wave * 1024), 16, dvoff[2], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(stg + 24576 + wave * 1024), 16, dvoff[3], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(stg + 32768 + (wave & 3) * 1024), 16, dvoff[4], so, 0, 0);
+  for (int a = 0; a < AB; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const unsigned vo = lane * 16;
+  const char* ua = p.A + (long long)((row0 >> 5) + AB * wave) * p.rba;
+  const char* ub = p.B + (long long)(col0 >> 5) * p.rbb;
+  const int rba = (int)p.rba, rbb = (int)p.rbb;
+  V16 FA[3][AB][2], FB[3][4][2];
+  auto rsrc_at = [&](const char* base, int tile) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base + (long long)min(tile, nkt - 1) * 2048), 0, 0x7fffffff, 0x00020000);
   };
-
-  // ---- fragment addresses: row r = lane & 15, k-group g = lane >> 4 -> chunk (half g & 1, part s(g))
-  const int fr = lane & 15, g = lane >> 4, fh = g & 1, hi = g >> 1;
-  const int o01 = fr * 96 + (fh * 3 + (hi ? 1 : 0)) * 16;        // [part 0 | part 1]
-  const int o02 = fr * 96 + (fh * 3 + (hi ? 2 : 0)) * 16;        // [part 0 | part 2]
-  const int o10 = fr * 96 + (fh * 3 + (hi ? 0 : 1)) * 16;        // [part 1 | part 0]
-  const int o20 = fr * 96 + (fh * 3 + (hi ? 0 : 2)) * 16;        // [part 2 | part 0]
-  const int abase = wm * 64 * 96, bbase = V2_BOFF + wn * 64 * 96;
-  auto ld = [&](const char* q) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const V16*>(q)); };
-
-  f4v acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f4v{0.f, 0.f, 0.f, 0.f};
-
-  bf16x8 AX[4], AY[4];                  // A fragments of the current k-tile, one row block each: [a0|a1], [a0|a2]
-  bf16x8 BU[2][4], BV[2][4], BZ[2][4];  // B fragments, current and next k-tile: [b1|b0], [b2|b0], [b0|b1]
-
-  dma(0);
-  dma(1);
-  dma(2);
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // k-tile 0 has landed (this wave's part)
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const char* q = lds + bbase + b * 16 * 96;
-    BU[0][b] = ld(q + o10); BV[0][b] = ld(q + o20); BZ[0][b] = ld(q + o01);
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const char* q = lds + abase + a * 16 * 96;
-    AX[a] = ld(q + o01); AY[a] = ld(q + o02);
-  }
-
-#ifndef GPK_K5S2_SCHED
-#define GPK_K5S2_SCHED 1
-#endif
-  auto body = [&](int kt, auto curc) {
-    constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
-    // k-tile kt+1 must be complete in LDS for every wave before anybody reads it; k-tile kt+2 stays in flight
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    dma(kt + 3);                        // into the stage whose fragments were read two barriers ago
-    const char* nb = lds + ((kt + 1) & (V2_NSTG - 1)) * V2_STAGE;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      // the next k-tile's B fragments of column block a, read while this row block multiplies
-      {
-        const char* q = nb + bbase + a * 16 * 96;
-        BU[nxt][a] = ld(q + o10); BV[nxt][a] = ld(q + o20); BZ[nxt][a] = ld(q + o01);
-      }
-      // smallest terms first: (a0 b2 + a2 b0), (a0 b1 + a1 b0), (a0 b0 + a1 b1)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AY[a], BV[cur][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AX[a], BU[cur][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AX[a], BZ[cur][b], acc[a][b], 0, 0, 0);
-      // this row block's A fragments of the next k-tile replace the ones just used
-      {
-        const char* q = nb + abase + a * 16 * 96;
-        AX[a] = ld(q + o01); AY[a] = ld(q + o02);
-      }
-    }
-#if GPK_K5S2_SCHED
-    // issue order: the 20 fragment reads of the next k-tile and the five DMAs spread evenly under the first 40 of the 48
-    // MFMAs (left alone, the scheduler puts all the reads behind the last MFMA: every wave then hits LDS at once and
-    // the next k-tile starts with a wait)
-#pragma unroll
-    for (int i = 0; i < 20; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (i % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#endif
+  auto ldf = [&](const __amdgpu_buffer_rsrc_t rs, int blk_off, V16 (&f)[2]) {
+    f[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, blk_off, 0);
+    f[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, blk_off + 1024, 0);
   };
-  for (int kt = 0; kt < nkt; kt += 2) {   // nkt is a multiple of 16
+  auto fill = [&](int tile, auto slc) {          // prologue: a whole k-tile, in the order the MFMAs will want it
+    constexpr int S = decltype(slc)::value;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_at(ua, tile), rb = rsrc_at(ub, tile);
+    ldf(ra, 0, FA[S][0]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ldf(rb, b * rbb, FB[S][b]);
+#pragma unroll
+    for (int a = 1; a < AB; ++a) ldf(ra, a * rba, FA[S][a]);
+  };
+  auto mm = [&](f16v& c, const V16 (&fa)[2], const V16 (&fb)[2]) {
+    const f16x8 a0 = __builtin_bit_cast(f16x8, fa[0]), a1 = __builtin_bit_cast(f16x8, fa[1]);
+    const f16x8 b0 = __builtin_bit_cast(f16x8, fb[0]), b1 = __builtin_bit_cast(f16x8, fb[1]);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);       // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+  };
+  fill(0, IntC<0>{});
+  fill(1, IntC<1>{});
+  fill(2, IntC<2>{});
+  auto body = [&](int kt, auto slc) {
+    constexpr int S = decltype(slc)::value;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_at(ua, kt + 3), rb = rsrc_at(ub, kt + 3);
+#pragma unroll
+    for (int a = 0; a < AB; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        mm(acc[a][b], FA[S][a], FB[S][b]);
+        if (a == AB - 1) ldf(rb, b * rbb, FB[S][b]);      // last use of this k-tile's B fragment: refill it
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ldf(ra, a * rba, FA[S][a]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int kt = 0, since = 0;
+  for (; kt + 3 <= nkt; kt += 3) {
     body(kt, IntC<0>{});
     body(kt + 1, IntC<1>{});
+    body(kt + 2, IntC<2>{});
+    if (p.sync_every > 0 && (since += 3) >= p.sync_every) { since = 0; __builtin_amdgcn_s_barrier(); }
+  }
+  if (kt < nkt) {
+    body(kt, IntC<0>{});
+    if (kt + 1 < nkt) body(kt + 1, IntC<1>{});
   }
 
   // ---- epilogue: per-column sums of squares of the tile (fp64), out[tile row][column]
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the clamped tail DMAs and the last fragment reads
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  double* red = reinterpret_cast<double*>(lds);      // [4][128]
+  __shared__ double red[4 * 128];
+  const float alpha = 1.0f / (p.wscale[(row0 + 32 * AB * wave) >> 7] * p.kscale);     // powers of two: exact
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     float s = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < AB; ++a)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const float v = p.alpha * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
-    s += __shfl_xor(s, 16, 64);
+      for (int i = 0; i < 16; ++i) { const float v = alpha * acc[a][b][i]; s = __builtin_fmaf(v, v, s); }
     s += __shfl_xor(s, 32, 64);
-    if (lane < 16) red[wm * 128 + wn * 64 + b * 16 + lane] = (double)s;
+    if (lane < 32) red[wave * 128 + 32 * b + lane] = (double)s;
   }
   __syncthreads();
-  if (tid < 128) {
-    double t2 = 0.0;
+  if (tid < 128) p.out[(long long)tm * p.Mp + col0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+}
+
+// fragment-order fp16 x 2 split of a row-major fp32 matrix: one wave per (32-row block, k16 block) = one MFMA operand pair;
+// lane = h * 32 + r reads the eight values of (row r, k half h) and writes its two chunks: each wave instruction of the
+// store writes 1 KiB of contiguous output.  scales: one power of two per 128-row block (device).
+__global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ src, long long rows, long long cols,
+                                                      long long ld, const float* __restrict__ scales,
+                                                      V16* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long KB = cols >> 4;
+  const long long kb = (long long)blockIdx.x * 4 + wave, rb = blockIdx.y;
+  if (kb >= KB) return;
+  const int r = lane & 31, h = lane >> 5;
+  const long long row = rb * 32 + r;
+  const float sc = scales[row >> 7];
+  const float4* s4 = reinterpret_cast<const float4*>(src + row * ld + kb * 16 + h * 8);
+  const float4 lo = s4[0], hi = s4[1];
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  f16x8 p0, p1;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) t2 += red[w * 128 + tid];
-    p.out[(long long)tm * p.Mp + col0 + tid] = t2;
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * sc;
+    const _Float16 h0 = (_Float16)x;
+    p0[j] = h0;
+    p1[j] = (_Float16)(x - (float)h0);
   }
+  V16* d = dst + ((rb * KB + kb) * 2) * 64 + lane;
+  d[0] = __builtin_bit_cast(V16, p0);
+  d[64] = __builtin_bit_cast(V16, p1);
+}
+
+// per 128-row block of a square fp32 matrix: max |A_ij| over the lower triangle (one row per workgroup, one atomic per
+// wave), then the power of two that puts that maximum in [2^14, 2^15]
+__global__ __launch_bounds__(256) void tril_block_absmax_kernel(const float* __restrict__ A, long long n, long long lda,
+                                                                unsigned* __restrict__ out) {
+  const long long i = blockIdx.x;
+  float m = 0.f;
+  for (long long jj = threadIdx.x; jj <= i; jj += 256) m = fmaxf(m, fabsf(A[i * lda + jj]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out + (i >> 7), __float_as_uint(m));
+}
+__global__ void absmax_to_scale_kernel(unsigned* __restrict__ io, int nblk) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const unsigned u = io[b];                     // bits of a non-negative float
+  const int e = (int)(u >> 23) - 127;           // max = 2^e * m, 1 <= m < 2
+  float s = 1.f;
+  if (u != 0u && u < 0x7f800000u) {
+    const int se = ((u & 0x7fffffu) == 0u ? 15 : 14) - e;          // largest power of two with s * max <= 2^15
+    s = __uint_as_float((unsigned)(min(max(se, -126), 127) + 127) << 23);
+  }
+  reinterpret_cast<float*>(io)[b] = s;
 }
 
 }  // namespace
@@ -691,82 +469,94 @@ extern "C" int gpk_split3(gpk_handle h, const float* src, int64_t rows, int64_t 
   return GPK_OK;
 }
 
-extern "C" int gpk_tril_absmax(gpk_handle h, const float* A, int64_t n, int64_t lda, double* out) {
+extern "C" int gpk_split2_rows(gpk_handle h, const float* W, int64_t n, int64_t ld, float* scales, void* dst) {
   if (!h) return GPK_BAD_ARG;
-  GPK_REQUIRE(h, A && out && n >= 1 && lda >= n && n < (1ll << 31), "tril_absmax: bad argument");
-  unsigned* d = reinterpret_cast<unsigned*>(h->d_small);
-  GPK_CHECK_HIP(h, hipMemsetAsync(d, 0, sizeof(unsigned), h->stream));
-  hipLaunchKernelGGL(tril_absmax_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, A, (long long)n, (long long)lda, d);
+  GPK_REQUIRE(h, W && scales && dst, "split2_rows: null pointer");
+  GPK_REQUIRE(h, n >= 128 && n % 128 == 0 && ld >= n && ld % 4 == 0 && n < (1ll << 24), "split2_rows: n must be a multiple of 128");
+  GPK_REQUIRE(h, ((uintptr_t)W % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split2_rows: buffers must be 16-byte aligned");
+  const int nblk = (int)(n / 128);
+  GPK_CHECK_HIP(h, hipMemsetAsync(scales, 0, nblk * sizeof(float), h->stream));
+  hipLaunchKernelGGL(tril_block_absmax_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, W, (long long)n, (long long)ld,
+                     reinterpret_cast<unsigned*>(scales));
   GPK_LAUNCH_CHECK(h);
-  unsigned bits = 0;
-  GPK_CHECK_HIP(h, hipMemcpyAsync(&bits, d, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-  float f;
-  memcpy(&f, &bits, sizeof f);
-  *out = (double)f;
-  return GPK_OK;
-}
-
-extern "C" int gpk_split2(gpk_handle h, const float* src, int64_t rows, int64_t cols, int64_t ld, double scale, void* dst) {
-  if (!h) return GPK_BAD_ARG;
-  GPK_REQUIRE(h, src && dst, "split2: null pointer");
-  GPK_REQUIRE(h, rows >= 4 && rows % 4 == 0 && cols >= 16 && cols % 16 == 0 && ld >= cols && ld % 4 == 0,
-              "split2: rows must be a multiple of 4 and cols a multiple of 16");
-  GPK_REQUIRE(h, ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split2: buffers must be 16-byte aligned");
-  int ex = 0;
-  GPK_REQUIRE(h, scale > 0.0 && std::frexp(scale, &ex) == 0.5, "split2: scale must be a power of two");
-  const long long n = rows * (cols / 8);
-  hipLaunchKernelGGL(split2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, (long long)rows,
-                     (long long)cols, (long long)ld, (float)scale, (V16*)dst);
+  hipLaunchKernelGGL(absmax_to_scale_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, h->stream,
+                     reinterpret_cast<unsigned*>(scales), nblk);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(split2_kernel, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)(n / 32)), dim3(256), 0, h->stream, W,
+                     (long long)n, (long long)n, (long long)ld, (const float*)scales, (V16*)dst);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }
 
-extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
-                                          const void* W2, double w_scale, int64_t Np, const float* Xq, int64_t M,
-                                          double kss, double floor_, float* work, void* work2, double* var) {
-  if (!h) return GPK_BAD_ARG;
-  GPK_REQUIRE(h, X && W2 && Xq && work && work2 && var, "predict_var_inv_split2: null pointer");
-  GPK_REQUIRE(h, N >= 1 && M >= 1 && Np == gpk_padded(N), "predict_var_inv_split2: Np must equal gpk_padded(N)");
-  GPK_REQUIRE(h, h->batch == 1, "predict_var_inv_split2: not available in batched mode");
-  GPK_REQUIRE(h, w_scale > 0.0 && sf2 > 0.0, "predict_var_inv_split2: scales must be positive");
+namespace {
+// K* in split form + the one launch of the fp16 x 2 form: column sums of squares by tile row in *partial ([*S][Mp])
+int split2_launch(gpk_handle h, const char* who, const float* X, int64_t N, int D, const double* ls, double sf2, const void* W2,
+                  const float* w_scales, int64_t Np, const float* Xq, int64_t M, void* work2, void** partial, int* S) {
+  GPK_REQUIRE(h, X && W2 && w_scales && Xq && work2, (std::string(who) + ": null pointer").c_str());
+  GPK_REQUIRE(h, N >= 1 && M >= 1 && Np == gpk_padded(N), (std::string(who) + ": Np must equal gpk_padded(N)").c_str());
+  GPK_REQUIRE(h, h->batch == 1, (std::string(who) + ": not available in batched mode").c_str());
+  GPK_REQUIRE(h, sf2 > 0.0 && D >= 1 && D <= 16, (std::string(who) + ": sf2 must be positive and D <= 16").c_str());
   const int64_t Mp = gpk_padded(M);
   const int ntm = (int)(Np / 128), ntn = (int)(Mp / 128);
-  // (buffer offsets are 32-bit: a tile's last row quad lies (TMR / 4) * 16 Np bytes beyond its first - at most 2048 Np)
-  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 2048 < (1ll << 31), "predict_var_inv_split2: size too large");
+  // (a fragment's byte offset inside a wave's AB row blocks is 32-bit: AB * Np * 128 bytes)
+  GPK_REQUIRE(h, (long long)ntm * ntn < (1ll << 30) && Np * 128 * 4 < (1ll << 31) && Mp / 64 < 65536,
+              (std::string(who) + ": size too large").c_str());
   // K* in (0, sf2]: the power of two that puts sf2 just below 2^15
   const double k_scale = std::ldexp(1.0, 14 - (int)std::floor(std::log2(sf2)));
-  if (D <= 16 && Mp / 64 < 65536) {
-    // K* computed and written in split form in one pass (`work` stays unused)
-    GPK_TRY(gpk_cross_split2(h, Xq, M, X, N, D, ls, sf2, k_scale, work2));
-  } else {
-    GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
-    GPK_TRY(gpk_split2(h, work, Mp, Np, Np, k_scale, work2));
-  }
-  // 512 x 128 tiles (128 x 64 per wave) when they come in at least two rounds of the 256 CUs; 256 x 128 or 128 x 128
-  // tiles (64 x 64 per wave) otherwise.  Option "k5_split2_tile": 0 = this rule, 1 = always 64 x 64 per wave, 2 = 512 x 128
-  // whenever Np allows.
-  const bool big_ok = Np % 512 == 0;
-  const bool big = big_ok && (h->k5_split2_tile == 2 || (h->k5_split2_tile == 0 && (Np / 512) * (long long)ntn >= 512));
-  const int ab = big ? 4 : 2;
-  const int wr = big ? 4 : ((Np % 256 == 0) ? 4 : 2);
-  const int ntmT = (int)(Np / (32 * ab * wr)), gsz = wr == 2 ? 64 : 32;
-  void* partial = nullptr;
-  GPK_TRY(gpk_scratch(h, (size_t)ntmT * Mp * sizeof(double), &partial));
-  SParams p;
-  p.A = (const char*)W2; p.B = (const char*)work2; p.out = (double*)partial;
-  p.rsa = Np * 16; p.rsb = Np * 16; p.Mp = Mp;      // bytes between consecutive quads of rows (4 rows x 4 bytes per entry)
+  GPK_TRY(gpk_cross_split2(h, Xq, M, X, N, D, ls, sf2, k_scale, work2));
+  // the tallest tile (512 / 256 / 128 rows x 128 columns) that still comes in at least two rounds of the 256 CUs
+  int ab = 1;
+  if (Np % 512 == 0 && (h->k5_split2_tile == 2 || (Np / 512) * (long long)ntn >= 512)) ab = 4;
+  else if (Np % 256 == 0 && (Np / 256) * (long long)ntn >= 512) ab = 2;
+  if (h->k5_split2_tile == 1) ab = 1;
+  const int ntmT = (int)(Np / (128 * ab)), gsz = 32;
+  GPK_TRY(gpk_scratch(h, (size_t)ntmT * Mp * sizeof(double), partial));
+  DParams p;
+  p.A = (const char*)W2; p.B = (const char*)work2; p.out = (double*)*partial; p.wscale = w_scales;
+  p.rba = p.rbb = Np * 128;      // bytes of one 32-row block
+  p.Mp = Mp;
+  p.kscale = (float)k_scale;
   p.ntm = ntm; p.ntn = ntn;
   p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
-  p.alpha = (float)(1.0 / (w_scale * k_scale));      // undo both operand scalings (powers of two: exact)
+  p.sync_every = h->k5_direct_sync;
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
   gpk_time_begin(h, GPK_TIMED_K5);
-  if (ab == 4) hipLaunchKernelGGL((k5_split_kernel<4, 2, 4>), dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
-  else if (wr == 4) hipLaunchKernelGGL((k5_split_kernel<4, 2>), dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
-  else hipLaunchKernelGGL((k5_split_kernel<2, 2>), dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
+  if (ab == 4) hipLaunchKernelGGL(k5_direct_kernel<4>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
+  else if (ab == 2) hipLaunchKernelGGL(k5_direct_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
+  else hipLaunchKernelGGL(k5_direct_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
   gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);
-  return gpk_colsum_finalize(h, (const double*)partial, ntmT, Mp, M, kss, floor_, var);
+  *S = ntmT;
+  return GPK_OK;
+}
+}  // namespace
+
+extern "C" int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
+                                          const void* W2, const float* w_scales, int64_t Np, const float* Xq, int64_t M,
+                                          double kss, double floor_, void* work2, double* var) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, var, "predict_var_inv_split2: null pointer");
+  void* partial = nullptr;
+  int S = 0;
+  GPK_TRY(split2_launch(h, "predict_var_inv_split2", X, N, D, ls, sf2, W2, w_scales, Np, Xq, M, work2, &partial, &S));
+  return gpk_colsum_finalize(h, (const double*)partial, S, gpk_padded(M), M, kss, floor_, var);
+}
+
+extern "C" int gpk_predict_mean_var_split2(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,
+                                           const double* ls, double sf2, const double* center, const double* y_mean,
+                                           const double* y_std, const void* W2, const float* w_scales, int64_t Np,
+                                           const float* Xq, int64_t M, double kss, double floor_, void* work2,
+                                           float* mean_tmp, double recheck_below, unsigned* low_count, double* out) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, alpha && y_mean && y_std && mean_tmp && out && P >= 1 && P <= GPK_MAX_P, "predict_mean_var_split2: bad argument");
+  // K4: the matrix-core kernel when the caller passes the expansion centre (it has checked max |u|^2), else exact differences
+  if (center) GPK_TRY(gpk_predict_mean_mfma(h, X, alpha, N, D, P, ls, sf2, center, y_mean, y_std, Xq, M, mean_tmp));
+  else GPK_TRY(gpk_predict_mean(h, GPK_F32, X, alpha, N, D, P, ls, sf2, y_mean, y_std, Xq, M, mean_tmp));
+  void* partial = nullptr;
+  int S = 0;
+  GPK_TRY(split2_launch(h, "predict_mean_var_split2", X, N, D, ls, sf2, W2, w_scales, Np, Xq, M, work2, &partial, &S));
+  return gpk_colsum_finalize_packed(h, (const double*)partial, S, gpk_padded(M), M, kss, floor_, mean_tmp, P, y_std,
+                                    recheck_below, low_count, out);
 }
 
 extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
@@ -782,11 +572,8 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   // Kq (Mp x Np, query-major, k contiguous) = k(Xq, X) in fp32, then its exact three-way bf16 split
   GPK_TRY(gpk_cross_gram_t(h, GPK_F32, Xq, M, X, N, D, ls, sf2, work, Np));
   GPK_TRY(gpk_split3(h, work, Mp, Np, Np, work3));
-#ifndef GPK_K5S_WR
-#define GPK_K5S_WR 4
-#endif
   // 256 x 128 tiles (8 waves, one workgroup per CU) when Np is a multiple of 256, else 128 x 128 (4 waves, two per CU)
-  const int wr = (GPK_K5S_WR == 4 && Np % 256 == 0) ? 4 : 2;
+  const int wr = (Np % 256 == 0) ? 4 : 2;
   const int ntmT = (int)(Np / (64 * wr)), gsz = wr == 2 ? 64 : 32;
   void* partial = nullptr;
   GPK_TRY(gpk_scratch(h, (size_t)ntmT * Mp * sizeof(double), &partial));
@@ -795,11 +582,9 @@ extern "C" int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N
   p.rsa = Np * 24; p.rsb = Np * 24; p.Mp = Mp;      // bytes between consecutive quads of rows
   p.ntm = ntm; p.ntn = ntn;
   p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
-  p.alpha = 1.0f;
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
   gpk_time_begin(h, GPK_TIMED_K5);
-  if (wr == 4 && h->k5_split_form == 2) hipLaunchKernelGGL(k5_split16_kernel, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
-  else if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
+  if (wr == 4) hipLaunchKernelGGL(k5_split_kernel<4>, dim3((unsigned)nblocks), dim3(512), 0, h->stream, p);
   else hipLaunchKernelGGL(k5_split_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
   gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);

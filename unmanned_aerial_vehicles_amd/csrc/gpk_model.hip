@@ -22,21 +22,22 @@ struct gpk_model {
   bool has_W = false;
   // fp32 serving copies (built on the first fp32 predict)
   float *Xf = nullptr, *alphaf = nullptr;
-  void* W3 = nullptr;            // fp16 x 2 split of W (gpk_split2) ...
-  double w_scale = 1.0;          // ... and the power of two it was scaled by
+  void* W3 = nullptr;            // fp16 x 2 split of W in fragment order (gpk_split2_rows) ...
+  float* w_scales = nullptr;     // ... and the power of two each 128-row block was scaled by
+  int f32_mean_ok = -1;          // fp32 serving gate on the mean (-1: not evaluated for the current alpha)
   // scratch of gpk_lml: a second factorisation that leaves the fitted one alone
   double *sK = nullptr, *sW = nullptr, *sKinv = nullptr, *sT = nullptr, *swinv = nullptr, *salpha = nullptr;
   // query staging
-  void *q = nullptr, *mean = nullptr, *work = nullptr, *work3 = nullptr;
+  void *q = nullptr, *mean = nullptr, *work = nullptr, *work3 = nullptr, *q64 = nullptr;
   double* var = nullptr;
-  size_t q_bytes = 0, mean_bytes = 0, work_bytes = 0, work3_bytes = 0, var_bytes = 0;
+  size_t q_bytes = 0, mean_bytes = 0, work_bytes = 0, work3_bytes = 0, var_bytes = 0, q64_bytes = 0;
 };
 
 namespace {
 
 void free_all(gpk_model* m) {
-  void* ptrs[] = {m->X, m->Yn, m->K, m->winv, m->W, m->alpha, m->Xf, m->alphaf, m->W3, m->sK, m->sW, m->sKinv, m->sT,
-                  m->swinv, m->salpha, m->q, m->mean, m->work, m->work3, m->var};
+  void* ptrs[] = {m->X, m->Yn, m->K, m->winv, m->W, m->alpha, m->Xf, m->alphaf, m->W3, m->w_scales, m->sK, m->sW, m->sKinv, m->sT,
+                  m->swinv, m->salpha, m->q, m->mean, m->work, m->work3, m->q64, m->var};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
 }
@@ -90,6 +91,79 @@ bool mfma_mean_admissible(const double* X, int64_t N, int D, int P, const double
     if (s > r2) r2 = s;
   }
   return P <= 8 && 0.5 * 1.4426950408889634 * r2 <= 64.0;
+}
+
+// rows i_s = round(s (N - 1) / (S - 1)) of X (N x D) -> q (S x D)
+__global__ void gather_rows_kernel(const double* __restrict__ X, long long N, int D, int S, double* __restrict__ q) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= S * D) return;
+  const int s = e / D, d = e - s * D;
+  const long long i = S > 1 ? (long long)llrint((double)s * (double)(N - 1) / (double)(S - 1)) : 0;
+  q[e] = X[i * D + d];
+}
+__global__ void square_kernel(const double* __restrict__ a, long long n, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] * a[i];
+}
+
+// ---- fp32 serving gates (the rule of DeviceGP.predict_gated_dev, device.py) ------------------------------------------
+// An fp32 kernel value carries the rounding of its exponent, so every term k*_j alpha_j of the mean is off by a few 1e-7
+// of itself with random sign: mean error ~ c sqrt(sum_j (k*_j alpha_j)^2), c = 4.0e-7 for the matrix-core kernel and
+// 9.0e-7 for the exact-difference kernel (worst query per batch over 41 random models: profiles/r02_fp32_gate_calibration.log).
+// A2 = max_m sqrt(sum_j (k_mj alpha_j)^2) / max_m |mean_m| is measured on <= 1024 evenly spaced training rows (where it is
+// largest) with two fp64 K4 launches - the second with the squared kernel (length-scales / sqrt 2, sf2^2) and squared
+// weights - once per alpha; a model with c A2 above 1e-4 is served by the fp64 kernels.
+constexpr double F32_MEAN_C_MFMA = 4.0e-7, F32_MEAN_C_VALU = 9.0e-7, F32_MEAN_TOL = 1e-4;
+// fp32 variances below this fraction of the prior variance are recomputed in fp64 (their relative error is the absolute
+// error of |W k*|^2 - up to 4e-5 kss - over the variance itself)
+constexpr double F32_VAR_RECHECK_FRACTION = 1e-2;
+
+int f32_mean_gate(gpk_handle h, gpk_model* m, bool* ok) {
+  if (m->f32_mean_ok >= 0) { *ok = m->f32_mean_ok != 0; return GPK_OK; }
+  const int D = m->D, P = m->P, S = (int)(m->N < 1024 ? m->N : 1024);
+  double *q = nullptr, *a2 = nullptr, *o1 = nullptr, *o2 = nullptr;
+  int rc = GPK_OK;
+  if (hipMalloc((void**)&q, (size_t)S * D * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&a2, (size_t)m->N * P * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&o1, (size_t)S * P * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&o2, (size_t)S * P * sizeof(double)) != hipSuccess) {
+    h->err = "fp32 mean gate: hipMalloc failed";
+    rc = GPK_HIP_ERROR;
+  }
+  std::vector<double> h1((size_t)S * P), h2((size_t)S * P);
+  if (rc == GPK_OK) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((S * D + 255) / 256)), dim3(256), 0, h->stream, m->X,
+                       (long long)m->N, D, S, q);
+    const long long na = m->N * P;
+    hipLaunchKernelGGL(square_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, h->stream, m->alpha, na, a2);
+    double zeros[GPK_MAX_P] = {0}, ones[GPK_MAX_P], ls2[GPK_MAX_D_PREDICT];
+    for (int p = 0; p < GPK_MAX_P; ++p) ones[p] = 1.0;
+    for (int d = 0; d < D; ++d) ls2[d] = m->ls[d] / std::sqrt(2.0);
+    rc = gpk_predict_mean(h, GPK_F64, m->X, m->alpha, m->N, D, P, m->ls, m->sf2, zeros, ones, q, S, o1);
+    if (rc == GPK_OK) rc = gpk_predict_mean(h, GPK_F64, m->X, a2, m->N, D, P, ls2, m->sf2 * m->sf2, zeros, ones, q, S, o2);
+    if (rc == GPK_OK &&
+        (hipMemcpyAsync(h1.data(), o1, h1.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+         hipMemcpyAsync(h2.data(), o2, h2.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+         hipStreamSynchronize(h->stream) != hipSuccess)) {
+      h->err = "fp32 mean gate: copy failed";
+      rc = GPK_HIP_ERROR;
+    }
+  }
+  for (void* ptr : {(void*)q, (void*)a2, (void*)o1, (void*)o2})
+    if (ptr) (void)hipFree(ptr);
+  GPK_TRY(rc);
+  double amp = 0.0;
+  for (int p = 0; p < P; ++p) {
+    double b = 0.0, a = 0.0;
+    for (int s2 = 0; s2 < S; ++s2) {
+      b = std::fmax(b, std::fabs(h1[(size_t)s2 * P + p]));
+      a = std::fmax(a, h2[(size_t)s2 * P + p]);
+    }
+    amp = std::fmax(amp, std::sqrt(a) / std::fmax(b, 1e-300));
+  }
+  m->f32_mean_ok = ((m->mfma_mean_ok ? F32_MEAN_C_MFMA : F32_MEAN_C_VALU) * amp <= F32_MEAN_TOL) ? 1 : 0;
+  *ok = m->f32_mean_ok != 0;
+  return GPK_OK;
 }
 
 int set_hyper(gpk_handle h, gpk_model* m, const double* ls, int n_ls, double sf2, double noise, double jitter) {
@@ -224,6 +298,20 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
   // sklearn surface: k** = sf2 + noise (Sum.diag), clipped at 0; package surface: k** = sf2, floored at 1e-10
   const double kss = m->sf2 + (var_includes_noise ? m->noise : 0.0), floor_ = var_includes_noise ? 0.0 : 1e-10;
   if (var) GPK_TRY(ensure_W(h, m));
+  if (f32) {
+    // fp32 serving is gated: a model whose fp32 mean would leave the stated 1e-4 is served by the fp64 kernels
+    bool ok = true;
+    GPK_TRY(f32_mean_gate(h, m, &ok));
+    if (!ok) {
+      std::vector<double> q64((size_t)M * D), m64((size_t)M * P), v64(var ? (size_t)M * P : 0);
+      for (int64_t i = 0; i < M * D; ++i) q64[(size_t)i] = (double)((const float*)Xq)[i];
+      GPK_TRY(gpk_predict(h, q64.data(), M, m64.data(), var ? v64.data() : nullptr, GPK_F64, var_includes_noise));
+      for (int64_t i = 0; i < M * P; ++i) ((float*)mean)[i] = (float)m64[(size_t)i];
+      if (var)
+        for (int64_t i = 0; i < M * P; ++i) ((float*)var)[i] = (float)v64[(size_t)i];
+      return GPK_OK;
+    }
+  }
   // control-loop batches, fp64: the one-call serving path (two launches up to 32 rows)
   if (!f32 && M <= 64 && (!var || m->Np <= GPK_SMALL_MAX_NP)) {
     std::vector<double> v1((size_t)M);
@@ -247,13 +335,10 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
     float* Wf = nullptr;
     GPK_CHECK_HIP(h, hipMalloc((void**)&Wf, (size_t)m->Np * m->Np * sizeof(float)));
     int rc = gpk_tril_to_f32(h, m->W, m->Np, m->Np, Wf, m->Np);
-    double wmax = 0.0;
-    if (rc == GPK_OK) rc = gpk_tril_absmax(h, Wf, m->Np, m->Np, &wmax);
-    if (rc == GPK_OK) {
-      m->w_scale = std::ldexp(1.0, (int)std::floor(std::log2(32768.0 / (wmax > 1e-300 ? wmax : 1e-300))));
-      rc = hipMalloc(&m->W3, (size_t)m->Np * m->Np * 4) == hipSuccess ? GPK_OK : GPK_HIP_ERROR;
-    }
-    if (rc == GPK_OK) rc = gpk_split2(h, Wf, m->Np, m->Np, m->Np, m->w_scale, m->W3);
+    if (rc == GPK_OK)
+      rc = (hipMalloc(&m->W3, (size_t)m->Np * m->Np * 4) == hipSuccess &&
+            hipMalloc((void**)&m->w_scales, (size_t)(m->Np / 128) * sizeof(float)) == hipSuccess) ? GPK_OK : GPK_HIP_ERROR;
+    if (rc == GPK_OK) rc = gpk_split2_rows(h, Wf, m->Np, m->Np, m->w_scales, m->W3);
     if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
     (void)hipFree(Wf);
     GPK_TRY(rc);
@@ -266,8 +351,8 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
   GPK_TRY(grow(h, &m->q, &m->q_bytes, (size_t)panel * D * es));
   GPK_TRY(grow(h, &m->mean, &m->mean_bytes, (size_t)panel * P * es));
   if (var) {
-    GPK_TRY(grow(h, &m->work, &m->work_bytes, (size_t)m->Np * panel * es));
-    if (f32) GPK_TRY(grow(h, &m->work3, &m->work3_bytes, (size_t)m->Np * panel * 4));
+    if (f32) GPK_TRY(grow(h, &m->work3, &m->work3_bytes, (size_t)m->Np * panel * 4));     // K* in split form only
+    else GPK_TRY(grow(h, &m->work, &m->work_bytes, (size_t)m->Np * panel * es));
     GPK_TRY(grow(h, (void**)&m->var, &m->var_bytes, (size_t)panel * sizeof(double) + (size_t)panel * P * es + GPK_MAX_P * sizeof(double)));
   }
   double* d_ystd = nullptr;
@@ -290,20 +375,45 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
     GPK_CHECK_HIP(h, hipMemcpyAsync((char*)mean + (size_t)m0 * P * es, m->mean, (size_t)mc * P * es, hipMemcpyDeviceToHost, h->stream));
     if (var) {
       if (f32)
-        GPK_TRY(gpk_predict_var_inv_split2(h, m->Xf, m->N, D, m->ls, m->sf2, m->W3, m->w_scale, m->Np, (const float*)m->q, mc,
-                                           kss, floor_, (float*)m->work, m->work3, m->var));
+        GPK_TRY(gpk_predict_var_inv_split2(h, m->Xf, m->N, D, m->ls, m->sf2, m->W3, m->w_scales, m->Np, (const float*)m->q, mc,
+                                           kss, floor_, m->work3, m->var));
       else
         GPK_TRY(gpk_predict_var_inv(h, GPK_F64, m->X, m->N, D, m->ls, m->sf2, m->W, m->Np, m->Np, m->q, mc, kss, floor_,
                                     m->work, m->var));
-      const long long tot = mc * P;
-      if (f32)
-        hipLaunchKernelGGL(scale_var_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, m->var,
-                           (long long)mc, P, d_ystd, (float*)d_varout);
-      else
+      if (f32) {
+        // fp32 variances that are a small fraction of the prior's are recomputed by the fp64 launch (F32_VAR_RECHECK_FRACTION)
+        std::vector<double> vh((size_t)mc);
+        GPK_CHECK_HIP(h, hipMemcpyAsync(vh.data(), m->var, (size_t)mc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+        std::vector<int64_t> low;
+        for (int64_t i = 0; i < mc; ++i)
+          if (vh[(size_t)i] < F32_VAR_RECHECK_FRACTION * kss) low.push_back(i);
+        for (size_t l0 = 0; l0 < low.size(); l0 += (size_t)panel) {
+          const int64_t lc = (int64_t)std::min(low.size() - l0, (size_t)panel);
+          std::vector<double> q64((size_t)lc * D), v2((size_t)lc);
+          for (int64_t i = 0; i < lc; ++i)
+            for (int d = 0; d < D; ++d) q64[(size_t)i * D + d] = (double)((const float*)Xq)[(size_t)(m0 + low[l0 + i]) * D + d];
+          GPK_TRY(grow(h, &m->work, &m->work_bytes, (size_t)m->Np * gpk_padded(lc) * sizeof(double)));
+          GPK_TRY(grow(h, &m->q64, &m->q64_bytes, (size_t)lc * D * sizeof(double) + (size_t)gpk_padded(lc) * sizeof(double)));
+          double* dq = (double*)m->q64;
+          double* dv = dq + (size_t)lc * D;
+          GPK_CHECK_HIP(h, hipMemcpyAsync(dq, q64.data(), q64.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+          GPK_TRY(gpk_predict_var_inv(h, GPK_F64, m->X, m->N, D, m->ls, m->sf2, m->W, m->Np, m->Np, dq, lc, kss, floor_,
+                                      m->work, dv));
+          GPK_CHECK_HIP(h, hipMemcpyAsync(v2.data(), dv, (size_t)lc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+          GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+          for (int64_t i = 0; i < lc; ++i) vh[(size_t)low[l0 + i]] = v2[(size_t)i];
+        }
+        for (int64_t i = 0; i < mc; ++i)      // undo the normalisation of the variance (sklearn/_gpr.py:487-489)
+          for (int p = 0; p < P; ++p)
+            ((float*)var)[(size_t)(m0 + i) * P + p] = (float)(vh[(size_t)i] * m->y_std[p] * m->y_std[p]);
+      } else {
+        const long long tot = mc * P;
         hipLaunchKernelGGL(scale_var_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, m->var,
                            (long long)mc, P, d_ystd, (double*)d_varout);
-      GPK_LAUNCH_CHECK(h);
-      GPK_CHECK_HIP(h, hipMemcpyAsync((char*)var + (size_t)m0 * P * es, d_varout, (size_t)mc * P * es, hipMemcpyDeviceToHost, h->stream));
+        GPK_LAUNCH_CHECK(h);
+        GPK_CHECK_HIP(h, hipMemcpyAsync((char*)var + (size_t)m0 * P * es, d_varout, (size_t)mc * P * es, hipMemcpyDeviceToHost, h->stream));
+      }
     }
     GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));     // the staging blocks are reused by the next panel
   }

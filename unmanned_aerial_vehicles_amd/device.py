@@ -455,24 +455,19 @@ class DeviceGP:
         return self._Winv["split"]
 
     def split2_inverse_factor(self):
-        """The fp32 inverse factor as two fp16 parts per entry (gpk_split2 layout, 4 bytes per entry) and the power
-        of two it was scaled by: the operand of the optional fast variance launch (`method="inverse_split2"`)."""
+        """The fp32 inverse factor as two fp16 parts per entry in fragment order (gpk_split2_rows: 4 bytes per entry, one
+        power-of-two scale per 128-row block, computed on the device): the operand of `method="inverse_split2"`."""
         torch = _torch()
         if "split2" not in self._Winv:
             had_f32 = "f32" in self._Winv
             Wf = self.inverse_factor(True)
             be = self.be
-            # largest |W_ij| over the lower triangle (what lies right of the zero band is not part of W)
-            wmax = C.c_double(0.0)
-            with be.lock:
-                be.bind_stream()
-                be.check(be.lib.gpk_tril_absmax(be.h, _p(Wf), self.Np, self.Np, C.byref(wmax)))
-            scale = 2.0 ** int(np.floor(np.log2(32768.0 / max(wmax.value, 1e-300))))
+            scales = be.empty((self.Np // 128,), torch.float32)
             W2 = be.empty((self.Np * self.Np * 4,), torch.uint8)
             with be.lock:
                 be.bind_stream()
-                be.check(be.lib.gpk_split2(be.h, _p(Wf), self.Np, self.Np, self.Np, float(scale), _p(W2)))
-            self._Winv["split2"] = (W2, float(scale))
+                be.check(be.lib.gpk_split2_rows(be.h, _p(Wf), self.Np, self.Np, _p(scales), _p(W2)))
+            self._Winv["split2"] = (W2, scales)
             if not had_f32:
                 self._Winv.pop("f32", None)
         return self._Winv["split2"]
@@ -524,12 +519,12 @@ class DeviceGP:
         solve_triangular; a chain of 2 Np/128 - 1 GEMM launches); "inverse": |W k*|^2 with the
         explicit inverse factor W = L^-1, formed once per factorisation, in ONE fused GEMM launch (fp64 MFMA, or
         the exact-fp32 MFMA).  fp32 only - the same launch with the products on the 16-bit matrix pipe (fp32
-        accumulation, operands represented to fp32's own unit roundoff): "inverse_split2": every fp32 operand as two
-        round-to-nearest fp16 parts (a0 + a1 = a to 2^-24), block products a1 b0 + a0 b1 + a0 b0 (error <= 3 x 2^-24
-        per product, below the fp32 accumulation error; measured over 31 random models: the same |W k*|^2 error as the
-        exact-fp32 MFMA, profiles/r02_fp32_variance_forms_accuracy.log; 2.6x its speed); "inverse_split": three bf16
-        parts (exact), six products per block (1.5x the fp32 MFMA's speed).  "auto": "inverse" for fp64,
-        "inverse_split2" for fp32."""
+        accumulation): "inverse_split2": every fp32 operand as two round-to-nearest fp16 parts (a0 + a1 = a to 2^-23 at
+        worst; W scaled per 128-row block), block products a1 b0 + a0 b1 + a0 b0 (the dropped a1 b1 is below 2^-22 |a b|:
+        at most 2^-21 |a b| per product in the worst case, ~2^-24 rms; measured over 31 random models: the same |W k*|^2
+        error as the exact-fp32 MFMA, profiles/r02_fp32_variance_forms_accuracy.log; 2.9x its speed), operands in
+        fragment order loaded from L2 straight into registers; "inverse_split": three bf16 parts (exact), six products
+        per block (1.5x the fp32 MFMA's speed).  "auto": "inverse" for fp64, "inverse_split2" for fp32."""
         torch = _torch()
         assert self.factored
         f32 = dtype in ("float32", np.float32, torch.float32)
@@ -551,7 +546,7 @@ class DeviceGP:
         if method == "inverse_split":
             W3 = self.split_inverse_factor()
         elif method == "inverse_split2":
-            W2, w_scale = self.split2_inverse_factor()
+            W2, w_scales = self.split2_inverse_factor()
         elif method == "inverse":
             Wd = self.inverse_factor(f32)
         elif f32:
@@ -561,7 +556,7 @@ class DeviceGP:
             Ld, wd = self.K, self.winv
         panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * es)) // 128 * 128))
         panel = min(panel, padded(M))
-        work = self.be.empty((self.Np * panel,), tdt)
+        work = self.be.empty((self.Np * panel,), tdt) if method != "inverse_split2" else None     # (K* only ever exists split)
         work3 = (self.be.empty((self.Np * panel * (6 if method == "inverse_split" else 4),), torch.uint8)
                  if method in ("inverse_split", "inverse_split2") else None)
         var = self.be.empty((panel,), torch.float64)
@@ -577,8 +572,8 @@ class DeviceGP:
                                                               _p(work), _p(work3), _p(var)))
                 elif method == "inverse_split2":
                     be.check(be.lib.gpk_predict_var_inv_split2(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W2),
-                                                               w_scale, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
-                                                               float(floor), _p(work), _p(work3), _p(var)))
+                                                               _p(w_scales), self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
+                                                               float(floor), _p(work3), _p(var)))
                 elif method == "inverse":
                     be.check(be.lib.gpk_predict_var_inv(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Wd),
                                                         self.Np, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
@@ -588,6 +583,96 @@ class DeviceGP:
                                                     self.Np, self.Np, _p(wd), _p(q[m0:m1]), m1 - m0, float(kss),
                                                     float(floor), _p(work), _p(var)))
                 out[m0:m1].copy_(var[: m1 - m0])
+        return out
+
+    # ---- gated serving: the one place every fp32 surface (estimator, sharded predictor, package GP, per-axis models) goes
+    # through -------------------------------------------------------------------------------------------------------------
+    def _fp64_var_method(self):
+        return "inverse" if ("f64" in self._Winv or self.Np <= self.INVERSE_EAGER_NP) else "solve"
+
+    def _gate_mean(self, dtype, var_method, gated):
+        """(predict dtype, variance method) after the mean gate: an fp32 request for a model whose fp32 mean would leave
+        the stated 1e-4 is served by the fp64 kernels."""
+        torch = _torch()
+        f32 = dtype in ("float32", np.float32, torch.float32)
+        if f32 and gated and not self.fp32_mean_ok():
+            return "float64", ("auto" if var_method in ("inverse_split", "inverse_split2") else var_method)
+        return ("float32" if f32 else "float64"), var_method
+
+    def predict_gated_dev(self, Xq, y_mean, y_std, kss=None, floor=0.0, dtype="float64", var_method="auto", gated=True):
+        """K4 (+ K5 when `kss` is given) with the fp32 serving gates applied: (mean (M, P) tensor of the dtype it was
+        computed in, var (M,) float64 tensor in normalised-target units, or None).  dtype "float32" is a REQUEST: the mean gate (`fp32_mean_ok`) may
+        route the model to the fp64 kernels, and single queries whose fp32 variance is below FP32_VAR_RECHECK_FRACTION of
+        the prior's are recomputed by the fp64 launch.  gated=False: the raw fp32 kernels (tests, A/B timings)."""
+        torch = _torch()
+        pd, vm = self._gate_mean(dtype, var_method, gated)
+        q = self._as_queries(Xq, torch.float32 if pd == "float32" else torch.float64)
+        mean = self.predict_mean_dev(q, y_mean, y_std, pd)
+        if kss is None:
+            return mean, None
+        var = self.predict_var_dev(q, kss, floor, pd, vm)
+        if gated and pd == "float32" and q.shape[0]:
+            low = torch.nonzero(var < self.FP32_VAR_RECHECK_FRACTION * kss).ravel()
+            if low.numel():
+                q64 = (q[low].double() if isinstance(Xq, torch.Tensor)
+                       else self.be.upload(np.ascontiguousarray(Xq, dtype=np.float64)[low.cpu().numpy()]))
+                var[low] = self.predict_var_dev(q64.contiguous(), kss, floor, "float64", self._fp64_var_method())
+        return mean, var
+
+    def predict_packed_dev(self, Xq, y_mean, y_std, kss, floor=0.0, dtype="float32", var_method="auto", gated=True):
+        """One serving step, the whole result in one (M, 2P) float64 device tensor: row m = [mean_m | var_m y_std^2]
+        (un-normalised: what the all-gather of a sharded batch moves).  The fp32 default is ONE C call per panel
+        (gpk_predict_mean_var_split2: K4, K* in split form, the variance launch, a finalising kernel that un-normalises,
+        packs and counts the rows the variance gate must recompute); no torch arithmetic runs unless that count is
+        non-zero.  Other dtypes / methods: the separate launches and gpk_pack_mean_var."""
+        torch = _torch()
+        pd, vm = self._gate_mean(dtype, var_method, gated)
+        f32 = pd == "float32"
+        if vm == "auto":
+            vm = "inverse_split2" if f32 else "inverse"
+        q = self._as_queries(Xq, torch.float32 if f32 else torch.float64)
+        M = q.shape[0]
+        out = self.be.empty((M, 2 * self.P), torch.float64)
+        if M == 0:
+            return out
+        ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
+        ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
+        be = self.be
+        if not (f32 and vm == "inverse_split2"):
+            mean = self.predict_mean_dev(q, ym, ys, pd)
+            var = self.predict_var_dev(q, kss, floor, pd, vm)
+            if gated and f32:
+                low = torch.nonzero(var < self.FP32_VAR_RECHECK_FRACTION * kss).ravel()
+                if low.numel():
+                    var[low] = self.predict_var_dev(q[low].double().contiguous(), kss, floor, "float64", self._fp64_var_method())
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_pack_mean_var(be.h, GPK_F32 if f32 else GPK_F64, _p(mean), _p(var), M, self.P,
+                                                  ys.ctypes.data_as(_lib._dp), _p(out)))
+            return out
+        c = self._f32_data()
+        W2, w_scales = self.split2_inverse_factor()
+        center = self._xc.ctypes.data_as(_lib._dp) if self.mean_kernel_choice() == "mfma" else None
+        panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * 4)) // 128 * 128))
+        panel = min(panel, padded(M))
+        work2 = be.empty((self.Np * panel * 4,), torch.uint8)
+        mean_tmp = be.empty((panel * self.P,), torch.float32)
+        count = torch.zeros((1,), dtype=torch.int32, device=be.device) if gated else None
+        thr = self.FP32_VAR_RECHECK_FRACTION * kss if gated else 0.0
+        with be.lock:
+            be.bind_stream()
+            for m0 in range(0, M, panel):
+                m1 = min(M, m0 + panel)
+                be.check(be.lib.gpk_predict_mean_var_split2(
+                    be.h, _p(c["X"]), _p(c["alpha"]), self.N, self.D, self.P, self.ls.ctypes.data_as(_lib._dp), self.sf2,
+                    center, ym.ctypes.data_as(_lib._dp), ys.ctypes.data_as(_lib._dp), _p(W2), _p(w_scales), self.Np,
+                    _p(q[m0:m1]), m1 - m0, float(kss), float(floor), _p(work2), _p(mean_tmp), float(thr),
+                    _p(count) if gated else None, _p(out[m0:m1])))
+        if gated and int(count.item()):          # (a 4-byte read-back; rows to recompute are rare: near training points only)
+            ys2 = torch.as_tensor(ys ** 2, device=be.device)
+            low = torch.nonzero(out[:, self.P] < thr * float(ys[0] ** 2)).ravel()
+            v64 = self.predict_var_dev(q[low].double().contiguous(), kss, floor, "float64", self._fp64_var_method())
+            out[low, self.P:] = v64[:, None] * ys2[None, :]
         return out
 
     def gram_host(self, ls, sf2, diag_add):

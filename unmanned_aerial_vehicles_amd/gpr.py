@@ -230,31 +230,20 @@ class GaussianProcessRegressor:
                 mean, var = mean[:, 0], var[:, 0]
             return mean, np.sqrt(var)
         import torch
-        # fp32 serving is gated (DeviceGP, "fp32 serving gates"): a model whose mean would leave the stated 1e-4
-        # goes through the fp64 kernels, and so do single queries whose fp32 variance is too small a fraction of the
-        # prior's to carry a 1e-3-accurate standard deviation
-        pd = self.predict_dtype
-        gated = pd == "float32" and getattr(self, "fp32_gate", True)
-        vm = self.var_method
-        if gated and not dev.fp32_mean_ok():
-            pd = "float64"
-            vm = "auto" if vm in ("inverse_split", "inverse_split2") else vm      # (the split launches are fp32 forms)
-        q = dev.be.upload(X, torch.float32 if pd == "float32" else torch.float64)
-        mean_d = dev.predict_mean_dev(q, self._y_train_mean, self._y_train_std, pd).double()
+        # fp32 serving is gated (DeviceGP.predict_gated_dev): a model whose mean would leave the stated 1e-4 goes through
+        # the fp64 kernels, and so do single queries whose fp32 variance is too small a fraction of the prior's to carry a
+        # 1e-3-accurate standard deviation
+        gated = getattr(self, "fp32_gate", True)
+        kss = None
+        if return_std:
+            comp = self.kernel_.components()
+            kss = comp.sf2 + (comp.noise or 0.0)        # kernel_.diag(X): RBF diag + WhiteKernel level
+        mean_d, var_d = dev.predict_gated_dev(X, self._y_train_mean, self._y_train_std, kss, 0.0, self.predict_dtype,
+                                              self.var_method, gated)   # variance clipped at 0 (_gpr.py:479-485)
         if not return_std:
             mean = mean_d.cpu().numpy()
             return mean[:, 0] if mean.shape[1] == 1 else mean
-        comp = self.kernel_.components()
-        kss = comp.sf2 + (comp.noise or 0.0)        # kernel_.diag(X): RBF diag + WhiteKernel level
-        var_d = dev.predict_var_dev(q, kss, 0.0, pd, vm)   # clipped at 0 (_gpr.py:479-485)
-        if gated and pd == "float32":
-            low = torch.nonzero(var_d < dev.FP32_VAR_RECHECK_FRACTION * kss).ravel()
-            if low.numel():
-                q64 = dev.be.upload(X, torch.float64)[low].contiguous()
-                var_d[low] = dev.predict_var_dev(q64, kss, 0.0, "float64",
-                                                 "inverse" if ("f64" in dev._Winv or dev.Np <= dev.INVERSE_EAGER_NP)
-                                                 else "solve")
-        both = torch.cat([mean_d, var_d[:, None]], dim=1).cpu().numpy()              # one device->host copy
+        both = torch.cat([mean_d.double(), var_d[:, None]], dim=1).cpu().numpy()     # one device->host copy
         mean, var = both[:, :-1], both[:, -1]
         var = np.outer(var, self._y_train_std ** 2)
         if mean.shape[1] == 1:

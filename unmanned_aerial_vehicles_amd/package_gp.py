@@ -125,8 +125,9 @@ class GaussianProcess:
                 # small batches: one C call and one synchronisation (gpk_predict_host)
                 mean, var = dev.predict_host(X_test, zeros, ones, sf2, 1e-10)
                 return mean, np.tile(var.reshape(-1, 1), (1, self.output_dim))
-            mean = dev.predict_mean_dev(X_test, zeros, ones, self.predict_dtype)
-            var = dev.predict_var_dev(X_test, sf2, 1e-10, self.predict_dtype)
+            # (predict_dtype "float32" is a request: DeviceGP's serving gates may route the model, or single rows'
+            # variances, to the fp64 kernels)
+            mean, var = dev.predict_gated_dev(X_test, zeros, ones, sf2, 1e-10, self.predict_dtype)
             mean = mean.double().cpu().numpy()
             var = np.tile(var.cpu().numpy().reshape(-1, 1), (1, self.output_dim))
             return mean, var

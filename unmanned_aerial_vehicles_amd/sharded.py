@@ -101,32 +101,29 @@ def sharded_gram(X, ls, sf2, diag_add, world_size=None, rank=None, backend=None,
 
 
 class ShardedPredictor:
-    """Query-sharded posterior mean (+ variance) for a fitted `GaussianProcessRegressor`."""
+    """Query-sharded posterior mean (+ variance) for a fitted `GaussianProcessRegressor`.  dtype "float32" (the default)
+    is served through the gated predictors of `DeviceGP` (`predict_gated_dev` / `predict_packed_dev`): a model whose fp32
+    mean would leave the stated 1e-4 runs on the fp64 kernels on every rank (the gate is a property of the replicated
+    model, so all ranks decide alike), and low fp32 variances are recomputed in fp64 inside the owning rank."""
 
-    def __init__(self, gpr, group=None, dtype="float32"):
-        self.gpr, self.group, self.dtype = gpr, group, dtype
+    def __init__(self, gpr, group=None, dtype="float32", gated=True):
+        self.gpr, self.group, self.dtype, self.gated = gpr, group, dtype, gated
 
     def predict_mean(self, Xq):
         """Xq: (M, D) tensor or array, identical on every rank -> (M, P) device tensor."""
         g = self.gpr
         g._ensure_device()
         return sharded_predict(
-            lambda q: g._dev.predict_mean_dev(q, g._y_train_mean, g._y_train_std, self.dtype), Xq, self.group)
+            lambda q: g._dev.predict_gated_dev(q, g._y_train_mean, g._y_train_std, None, 0.0, self.dtype, "auto",
+                                               self.gated)[0], Xq, self.group)
 
     def predict_mean_var(self, Xq):
-        import torch
-
         g = self.gpr
         g._ensure_device()
         comp = g.kernel_.components()
         kss = comp.sf2 + (comp.noise or 0.0)
-        ystd2 = torch.as_tensor(np.asarray(g._y_train_std) ** 2, device=g._dev.be.device, dtype=torch.float64)
-
-        def local(q):
-            mean = g._dev.predict_mean_dev(q, g._y_train_mean, g._y_train_std, self.dtype).double()
-            var = g._dev.predict_var_dev(q, kss, 0.0, self.dtype)
-            return torch.cat([mean, var[:, None] * ystd2[None, :]], dim=1)
-
-        out = sharded_predict(local, Xq, self.group)
+        out = sharded_predict(
+            lambda q: g._dev.predict_packed_dev(q, g._y_train_mean, g._y_train_std, kss, 0.0, self.dtype, "auto", self.gated),
+            Xq, self.group)
         P = g._dev.P
         return out[:, :P], out[:, P:]

@@ -1,6 +1,7 @@
 """Per-output ARD GP trainer / loader — the reference's alternative offline trainer on MI355X.
 
-`GPTrainer.train_gp_models` mirrors `src/px4/gp_trainer.py:121-205`: 80/20 split with seed 42,
+`GPTrainer.load_training_data` mirrors `src/px4/gp_trainer.py:49-119` (flight_data_*.npz -> [state, control] rows and
+double-integrator residuals); `GPTrainer.train_gp_models` mirrors `src/px4/gp_trainer.py:121-205`: 80/20 split with seed 42,
 one independent GP per residual component, z-scored inputs and target,
 `C(1, fixed) * RBF(ls in R^D, bounds 0.1..10) + WhiteKernel(0.01, 1e-5..10)`, `alpha=1e-6`,
 3 optimiser restarts.  `PreTrainedGP.predict_residual` mirrors `src/px4/pretrained_gp.py:52-98`
@@ -87,6 +88,42 @@ class GPTrainer:
         self.model_dir = model_dir
         self.device = device
         self.gp_models, self.scalers_X, self.scalers_y, self.training_stats = {}, {}, {}, {}
+
+    def load_training_data(self, max_samples=None):
+        """`flight_data_*.npz` files of `data_dir` -> (X (n, 10) = [state_prev | control], y (n, 6) = residuals against the
+        double-integrator nominal model).  Mirrors `src/px4/gp_trainer.py:49-102`: every file carries `states_prev`
+        (n, 6), `controls` (n, 4), `states_next` (n, 6), `dt_values` (n,); residual = next - nominal(prev, control, dt);
+        `max_samples` draws rows without replacement from the GLOBAL NumPy RNG (`np.random.choice`, :94-97), as the
+        reference does.  The files are visited in sorted order (the reference's unsorted glob makes the row order
+        depend on the file system)."""
+        import glob
+        data_files = sorted(glob.glob(os.path.join(self.data_dir, "flight_data_*.npz")))
+        if not data_files:
+            raise FileNotFoundError(f"No training data found in {self.data_dir}")
+        all_X, all_y = [], []
+        for data_file in data_files:
+            with np.load(data_file) as data:
+                states_prev = np.asarray(data["states_prev"], dtype=np.float64)
+                controls = np.asarray(data["controls"], dtype=np.float64)
+                states_next = np.asarray(data["states_next"], dtype=np.float64)
+                dt_values = np.asarray(data["dt_values"], dtype=np.float64).reshape(-1)
+            n = len(states_prev)            # (the reference walks range(len(states_prev)))
+            nominal = self._nominal_dynamics(states_prev[:n], controls[:n], dt_values[:n, None])
+            all_X.append(np.concatenate([states_prev[:n], controls[:n]], axis=1))
+            all_y.append(states_next[:n] - nominal)
+        X, y = np.concatenate(all_X, axis=0), np.concatenate(all_y, axis=0)
+        if max_samples and len(X) > max_samples:
+            indices = np.random.choice(len(X), max_samples, replace=False)
+            X, y = X[indices], y[indices]
+        return X, y
+
+    @staticmethod
+    def _nominal_dynamics(state, control, dt):
+        """Double integrator (`gp_trainer.py:104-119`): pos + vel dt, vel + accel dt; rows at once (the same fp64
+        operations per element as the reference's per-row form)."""
+        state, control = np.asarray(state, dtype=np.float64), np.asarray(control, dtype=np.float64)
+        pos, vel, accel = state[..., :3], state[..., 3:6], control[..., :3]
+        return np.concatenate([pos + vel * dt, vel + accel * dt], axis=-1)
 
     def train_gp_models(self, X, y, test_size=0.2, n_restarts_optimizer=3, optimizer="fmin_l_bfgs_b", batched=True):
         """batched=True (default): the per-output models share X, so they are trained together — one fused
