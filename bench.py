@@ -438,13 +438,8 @@ def main():
         mine = out[:M].double() if use_dist else out.double()
         m64 = dev.predict_mean_dev(q32.double(), y_mean, y_std, "float64")
         if c4:
-            # worst of a MILLION queries: a query's fp32 error scales with |k* o alpha|_2, whose extreme over 10^6 queries
-            # is ~3x the typical one (1e-4 holds for batches up to 10^4 queries, 2e-4 for 10^6)
             e_mean = float((mine - m64).abs().max() / m64.abs().max())
-            e_typ = float((mine[:10000] - m64[:10000]).abs().max() / m64.abs().max())
-            parity = {"mean_max_rel_err_vs_fp64": e_mean, "mean_tol": 2e-4, "queries_checked": M,
-                      "mean_max_rel_err_first_10000_queries": e_typ, "mean_tol_10000_queries": 1e-4,
-                      "ok": e_mean < 2e-4 and e_typ < 1e-4}
+            parity = {"mean_max_rel_err_vs_fp64": e_mean, "mean_tol": 1e-4, "queries_checked": M, "ok": e_mean < 1e-4}
         else:
             v64 = dev.predict_var_dev(q32.double(), kss, 0.0, "float64", "inverse" if use_w else "solve")
             s64 = torch.sqrt(v64[:, None] * ystd2[None, :])

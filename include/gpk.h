@@ -229,8 +229,8 @@ GPK_API int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, i
  * gpk_split2_rows: W (dev n x ld fp32 inverse factor, gpk_tril_to_f32 output, n % 128 == 0) -> scales (dev float[n / 128]:
  * for each 128-row block the largest power of two s with s * max |W_ij| <= 2^15, the maximum taken over the block's part of
  * the lower triangle - computed on the device, no synchronisation) and dst (dev, n * n * 4 bytes): x s = h0 + h1 + r with
- * h0, h1 fp16 rounded to nearest, |r| <= 2^-23 |x s| while h1 is a normal number (entries within 2^-18 of their row
- * block's largest) and |r| <= 2^-25 absolutely below that; 16-byte chunks in fragment order: chunk (row, k16 block kb,
+ * h0, h1 fp16 rounded to nearest, |r| <= max(2^-23 |x s|, 2^-25) (relative for entries within 2^-17 of 2^15, absolute
+ * below that, where h1 is a subnormal fp16); 16-byte chunks in fragment order: chunk (row, k16 block kb,
  * k half h, part p) at index (((row / 32) * (n / 16) + kb) * 2 + p) * 64 + h * 32 + row % 32 - the 64 chunks of one
  * v_mfma_f32_32x32x16_f16 operand are 1 KiB of contiguous memory.
  * gpk_predict_var_inv_split2: the result of gpk_predict_var_inv(GPK_F32, ...) from W2 / w_scales = gpk_split2_rows of the

@@ -432,14 +432,14 @@ def test_split3_is_exact(be):
 
 def test_split2_rows_layout_and_scales(be):
     """gpk_split2_rows: per 128-row block the largest power of two s with s * max |W_ij| (lower triangle) <= 2^15, and
-    every entry x as two fp16 parts with x s = h0 + h1 to 2^-23 (entries within 2^-18 of the block's largest), stored in
-    fragment order: chunk (row, k16 block kb, k half h, part p) at (((row / 32) * KB + kb) * 2 + p) * 64 + h * 32 + row % 32."""
+    every entry x as two fp16 parts with |x s - h0 - h1| <= max(2^-23 |x s|, 2^-25) (the second part of an entry below
+    2^-2 is a subnormal fp16), stored in fragment order: chunk (row, k16 block kb, k half h, part p) at (((row / 32) * KB + kb) * 2 + p) * 64 + h * 32 + row % 32."""
     import torch
     n = 384
     g = torch.Generator(device="cpu").manual_seed(5)
     W = torch.randn((n, n), generator=g) * torch.exp(2.0 * torch.randn((n, n), generator=g))
     W[128:256] *= 2.0 ** -9                  # a row block of much smaller entries gets its own, larger scale
-    W[300, 17] = 4096.0                      # exactly a power of two: the scale puts it AT 2^15
+    W[300, 17] = 2.0 ** 20                   # exactly a power of two (and the block's largest): the scale puts it AT 2^15
     W = torch.tril(W) + torch.triu(torch.full((n, n), 1.0e30), 1)     # what lies above the diagonal must not count
     Wd = W.to(be.device).contiguous()
     scales = torch.zeros((n // 128,), dtype=torch.float32, device=be.device)
@@ -452,26 +452,24 @@ def test_split2_rows_layout_and_scales(be):
         m = np.abs(Wl[128 * b:128 * b + 128]).max()
         assert sc[b] == 2.0 ** np.floor(np.log2(32768.0 / m)), (b, sc[b], m)
         assert 16384.0 < sc[b] * m <= 32768.0
-    assert sc[2] * 4096.0 == 32768.0 and sc[1] > sc[0]
+    assert sc[2] * 2.0 ** 20 == 32768.0 and sc[1] > sc[0]
     raw = dst.cpu().numpy().view(np.float16).reshape(n // 32, n // 16, 2, 2, 32, 8)      # [rb][kb][part][h][r][j]
     parts = np.moveaxis(raw, 4, 1)                                                          # [rb][r][kb][part][h][j]
-    tot = (parts[:, :, :, 0].astype(np.float64) + parts[:, :, :, 1].astype(np.float64)).reshape(n, n)   # [row][16 kb + 8 h + j]
+    with np.errstate(invalid="ignore", over="ignore"):      # (what lies above the diagonal overflows: not part of W)
+        tot = (parts[:, :, :, 0].astype(np.float64) + parts[:, :, :, 1].astype(np.float64)).reshape(n, n)   # [row][16 kb + 8 h + j]
     want = Wl * sc[np.arange(n) // 128, None]
     low = np.tril(np.ones((n, n), dtype=bool))
-    rowmax = np.abs(want).max(axis=1, keepdims=True)
-    big = low & (np.abs(want) >= rowmax * 2.0 ** -18)
-    assert np.all(np.abs(tot - want)[big] <= 2.0 ** -23 * np.abs(want)[big])
-    assert np.all(np.abs(tot - want)[low & ~big] <= 2.0 ** -25)
+    assert np.all(np.abs(tot - want)[low] <= np.maximum(2.0 ** -23 * np.abs(want)[low], 2.0 ** -25))
 
 
-@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300), (8192, 4200), (4096, 16500)])
+@pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300), (8192, 4200), (4096, 16000)])
 def test_variance_16bit_split_paths(be, N, M):
     """K5 on the 16-bit matrix pipe against the fp64 path and the exact-fp32 MFMA path on the same queries: the bf16 x 3
     split (six exact products per block) and the fp16 x 2 split (three products; the fp32 default) are in the same fp32
     accuracy class - std within 1e-3 of fp64 (the stated fp32 tolerance) and within 2x of the fp32-MFMA path's own
     error - in super-tile mode (N = 5000: 40 x 2 tiles is direct; N = 3000 x 700: 24 x 6), with ragged sizes, and for every
     tile height of the fp16 x 2 launch (option "k5_split2_tile": 128-row tiles, forced 512-row tiles where Np % 512 == 0,
-    and the library's own rule - N = 4096 x 16500 queries: 8 x 129 tiles of 512 rows)."""
+    and the library's own rule - N = 4096 x 16000 queries: 8 x 125 tiles of 512 rows)."""
     from unmanned_aerial_vehicles_amd.device import DeviceGP
     rng = np.random.default_rng(N)
     X = rng.standard_normal((N, 9))

@@ -53,6 +53,21 @@ def _worker(rank, world, port, M, q):
             e_s = np.max(np.abs(np.sqrt(var) - ref_std) / ref_std)
             e_m2 = np.max(np.abs(mean2 - ref_mean)) / np.max(np.abs(ref_mean))
             ok = ok and mean.shape == (M, 3) and e_m < tm and e_s < ts and e_m2 < tm
+        # a low-noise model (noise = 1e-3) whose queries include training points: the fp32 request goes through the serving
+        # gates of DeviceGP on every rank (fp64 kernels for the mean if its fp32 error would leave 1e-4; fp64 recompute of
+        # the variances that are a small fraction of the prior's) and must meet the fp32 bars; the raw fp32 kernels
+        # (gated=False) must NOT be what served it
+        g2 = GaussianProcessRegressor(kernel=RBF(2.0) + WhiteKernel(1e-3), alpha=1e-8, normalize_y=True, optimizer=None,
+                                      device=rank).fit(X, Y)
+        Xq2 = np.vstack([X[:300], Xq[: max(M - 300, 1)]])
+        r_mean, r_std = g2.predict(Xq2, return_std=True)
+        mean, var = ShardedPredictor(g2, dtype="float32").predict_mean_var(Xq2)
+        mean, var = mean.cpu().numpy(), var.cpu().numpy()
+        e_m = np.max(np.abs(mean - r_mean)) / np.max(np.abs(r_mean))
+        e_s = np.max(np.abs(np.sqrt(var) - r_std) / r_std)
+        _, var_raw = ShardedPredictor(g2, dtype="float32", gated=False).predict_mean_var(Xq2)
+        e_raw = np.max(np.abs(np.sqrt(var_raw.cpu().numpy()) - r_std) / r_std)
+        ok = ok and e_m < 1e-4 and e_s < 1e-3 and e_raw > e_s
         one = torch.ones(1, device=torch.device("cuda", rank))
         dist.all_reduce(one)
         q.put((rank, bool(ok), int(one.item())))

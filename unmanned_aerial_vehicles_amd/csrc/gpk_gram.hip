@@ -401,10 +401,25 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(const T* __restrict__
 #pragma unroll
     for (int p = 0; p < PP; ++p) acc[q][p] = T(0);
   }
+  // fp32: two-level sums - `acc` runs over one staged round (128 terms) and is then added to `tot`: the rounding of an
+  // fp32 chain grows like its length (each add rounds at the magnitude of the running sum), and a single chain over a
+  // whole chunk was the largest term of the fp32 mean's error for large query batches (whose chunks are long)
+  constexpr bool TWO_LEVEL = sizeof(T) == 4;
+  T tot[PM_QPT][PP];
+#pragma unroll
+  for (int q = 0; q < PM_QPT; ++q)
+#pragma unroll
+    for (int p = 0; p < PP; ++p) tot[q][p] = T(0);
   const long long n0 = (long long)blockIdx.y * chunk;
   const long long n1 = min(N, n0 + chunk);
   for (long long jb = n0; jb < n1; jb += PM_TJ) {
     const int nj = (int)min((long long)PM_TJ, n1 - jb);
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+      for (int q = 0; q < PM_QPT; ++q)
+#pragma unroll
+        for (int p = 0; p < PP; ++p) { tot[q][p] += acc[q][p]; acc[q][p] = T(0); }
+    }
     __syncthreads();
     // stage [x/ls | 0.. | alpha | 0..] for the nj <= PM_TJ rows of this round
     for (int e = tid; e < nj * (DD + PP); e += 256) {
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(256) void predict_mean_kernel(const T* __restrict__
     if (qm[q] < M) {
 #pragma unroll
       for (int p = 0; p < PP; ++p)
-        if (p < P) partial[((long long)blockIdx.y * M + qm[q]) * P + p] = acc[q][p];
+        if (p < P) partial[((long long)blockIdx.y * M + qm[q]) * P + p] = TWO_LEVEL ? tot[q][p] + acc[q][p] : acc[q][p];
     }
   }
 }
@@ -595,9 +610,9 @@ __global__ void mean_reduce_kernel(const T* __restrict__ partial, int S, long lo
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= M * P) return;
   const int p = (int)(e % P);
-  T s = T(0);
-  for (int k = 0; k < S; ++k) s += partial[(long long)k * M * P + e];
-  mean[e] = T(ymean.v[p]) + T(ystd.v[p]) * (sf2 * s);
+  double s = 0.0;                     // (fp32 partials too: the S-term chain adds no rounding of its own)
+  for (int k = 0; k < S; ++k) s += (double)partial[(long long)k * M * P + e];
+  mean[e] = T(ymean.v[p]) + T(ystd.v[p]) * (sf2 * T(s));
 }
 
 // ---- column sums of squares (fp64 accumulation) -------------------------------------------------------
@@ -823,6 +838,9 @@ extern "C" int gpk_predict_mean(gpk_handle h, int dtype, const void* X, const vo
   // chunk serially - so those get chunks of 32 rows instead of 128
   const int64_t gran = (M <= 512 && N <= 16384) ? 32 : PM_TJ;
   int64_t S = (2048 + nqb - 1) / nqb;
+  // fp32: chunks of at most 2048 training points, whatever the batch size (a thread's fp32 sums stay short: 128 terms per
+  // round, 16 rounds; the partials of the chunks are then added in fp64)
+  if (dtype == GPK_F32 && S < (N + 2047) / 2048) S = (N + 2047) / 2048;
   const int64_t maxS = (N + gran - 1) / gran;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;

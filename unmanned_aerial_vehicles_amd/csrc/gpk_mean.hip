@@ -413,9 +413,9 @@ __global__ void mean_mfma_reduce_kernel(const float* __restrict__ partial, int S
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= M * P) return;
   const int p = (int)(e % P);
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += partial[(long long)k * M * P + e];
-  mean[e] = (float)ymean.v[p] + (float)ystd.v[p] * (sf2 * s);
+  double s = 0.0;                     // the partials of the training chunks are added in fp64
+  for (int k = 0; k < S; ++k) s += (double)partial[(long long)k * M * P + e];
+  mean[e] = (float)ymean.v[p] + (float)ystd.v[p] * (sf2 * (float)s);
 }
 
 typedef void (*mm_fn)(const float*, const float*, long long, int, F16, F16, const float*, long long, long long, float*);
@@ -468,6 +468,11 @@ extern "C" int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* 
   const int64_t nqb = (M + 128 * QB - 1) / (128 * QB);
   // split the training set so that the grid has >= ~1024 workgroups (2 resident per CU, 2 rounds)
   int64_t S = (1024 + nqb - 1) / nqb;
+  // chunks of at most 2048 training points, whatever the batch size: a lane's fp32 running sums then cover 64 terms each
+  // (every add rounds at the magnitude of the running sum, so the rounding of a chain grows like its length: with one
+  // chunk = the whole training set, 2048 terms per lane at N = 65 536, that was the largest part of the mean's fp32 error
+  // for batches of 10^6 queries - 1.3e-4 against 2.5e-5 for 10^4 queries, whose chunks are short)
+  if (S < (N + 2047) / 2048) S = (N + 2047) / 2048;
   const int64_t maxS = (N + MM_TJ - 1) / MM_TJ;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
