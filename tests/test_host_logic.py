@@ -227,6 +227,14 @@ def test_pretrained_gp_never_raises(tmp_path, trainer_ref):
     if not torch.cuda.is_available():
         m, s = pre.predict_residual(trainer_ref["Xq"][0, :6], trainer_ref["Xq"][0, 6:])
         assert np.array_equal(m, np.zeros(6)) and np.array_equal(s, np.full(6, 1e6))
+    # a file none of whose models can be converted counts as not loaded (all-or-nothing, like the reference's load)
+    junk = dict(d, gp_models={k: object() for k in d["gp_models"]})
+    with open(str(tmp_path / "junk.pkl"), "wb") as f:
+        pickle.dump({k: v for k, v in junk.items() if k != "gp_models"} | {"gp_models": {k: 3.14 for k in junk["gp_models"]}}, f)
+    bad = PreTrainedGP(str(tmp_path / "junk.pkl"))
+    assert not bad.is_loaded and not bad.gp_models
+    m, s = bad.predict_residual(np.zeros(6), np.zeros(4))
+    assert np.array_equal(m, np.zeros(6)) and np.array_equal(s, np.full(6, 1e6))
     missing = PreTrainedGP(str(tmp_path / "nope.pkl"))
     assert not missing.is_loaded
     m, s = missing.predict_residual(np.zeros(6), np.zeros(4))

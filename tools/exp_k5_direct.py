@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""A/B of the fp16 x 2 variance launch: LDS-staged 512 x 128 tiles (`inverse_split2`) against the fragment-order launch
-whose operands go from L2 straight into registers (`inverse_split2f`), same box, same factor, same queries.  First a
-correctness sweep over small shapes (every tile height, ragged N and M), then the headline shape: kernel time from the
-library's own event brackets, agreement of the two results, error against the fp64 kernels."""
+"""The variance launch (K5) at the headline shape, form by form, on one box: `split2[:n]` = the fp16 x 2 launch with its
+operands going from L2 straight into registers (the fp32 serving default; n = workgroup barrier every n k-tiles),
+`bf16x3` = the exact three-way bf16 split (LDS-staged), `fp32` = the exact-fp32 MFMA GEMM.  Kernel time from the
+library's own event brackets, agreement with the first form, error against the fp64 kernels.  With SWEEP=1 (default) a
+correctness sweep over small shapes first: every tile height of the fp16 x 2 launch, ragged N and M, a low-noise model.
+(Round 3's A/B against the round-2 LDS-staged fp16 x 2 kernel and the 16x16x32 variant: profiles/r03_k5_direct_forms_ab.log.)"""
 import os
 import sys
 
@@ -13,6 +15,7 @@ from unmanned_aerial_vehicles_amd import _lib  # noqa: E402
 from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend  # noqa: E402
 
 be = get_backend(0)
+METHOD = {"split2": "inverse_split2", "bf16x3": "inverse_split", "fp32": "inverse"}
 
 
 def model(N, noise=0.1, seed=0):
@@ -36,18 +39,13 @@ if os.environ.get("SWEEP", "1") == "1":
         q = queries(M)
         kss = 1.0 + (0.1 if N != 5000 else 1e-3)
         v64 = dev.predict_var_dev(q.double(), kss, 0.0, "float64", "inverse")
+        v32 = dev.predict_var_dev(q, kss, 0.0, "float32", "inverse")
         be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", tile))
         v2 = dev.predict_var_dev(q, kss, 0.0, "float32", "inverse_split2")
-        DeviceGP.SPLIT2F_LAYOUT = 1
-        vf = dev.predict_var_dev(q, kss, 0.0, "float32", "inverse_split2f")
-        DeviceGP.SPLIT2F_LAYOUT = 2
-        vg = dev.predict_var_dev(q, kss, 0.0, "float32", "inverse_split2f")
         be.check(be.lib.gpk_set_option(be.h, b"k5_split2_tile", 0))
         rel = lambda v: float(((v.sqrt() - v64.sqrt()).abs() / v64.sqrt()).max())  # noqa: E731
-        print(f"N={N} M={M} tile={tile}: std err vs fp64: lds {rel(v2):.2e}  direct {rel(vf):.2e}  direct16 {rel(vg):.2e};  "
-              f"max |direct - lds| / kss {float((vf - v2).abs().max()) / kss:.2e}  max |direct16 - lds| / kss "
-              f"{float((vg - v2).abs().max()) / kss:.2e}", flush=True)
-        assert rel(vf) < max(2 * rel(v2), 1e-5) and rel(vg) < max(2 * rel(v2), 1e-5), "direct launch disagrees"
+        print(f"N={N} M={M} tile={tile}: std err vs fp64: fp32 MFMA {rel(v32):.2e}  fp16x2 {rel(v2):.2e}", flush=True)
+        assert rel(v2) < max(2 * rel(v32), 1e-5), "fp16 x 2 launch disagrees"
         del dev
 
 if os.environ.get("HEADLINE", "1") == "1":
@@ -57,35 +55,32 @@ if os.environ.get("HEADLINE", "1") == "1":
     dev = model(N)
     q = queries(M)
     v64 = dev.predict_var_dev(q.double(), 1.1, 0.0, "float64", "inverse")
-    forms = os.environ.get("FORMS", "lds,direct:24,direct16:24,direct16:0,lds,direct:24,direct16:24").split(",")
+    forms = os.environ.get("FORMS", "split2:24,split2:0,bf16x3,fp32,split2:24").split(",")
+    names = {f.partition(":")[0] for f in forms}
     dev.inverse_factor(True)
     dev._Winv.pop("f64", None)
-    ops = {}
-    if any(f.startswith("lds") for f in forms):
-        ops["lds"] = dev.split2_inverse_factor()
-    for name, lay in (("direct", 1), ("direct16", 2)):
-        if any(f.partition(":")[0] == name for f in forms):
-            DeviceGP.SPLIT2F_LAYOUT = lay
-            ops[name] = dev.split2f_inverse_factor()
-            dev._Winv.pop("split2f")
-    dev._Winv.pop("f32", None)
+    if "split2" in names:
+        dev.split2_inverse_factor()
+    if "bf16x3" in names:
+        dev.split_inverse_factor()
+    if "fp32" not in names:
+        dev._Winv.pop("f32", None)
     ref = None
     for form in forms:
         name, _, sync = form.partition(":")
-        method = "inverse_split2" if name == "lds" else "inverse_split2f"
-        if name != "lds":
-            DeviceGP.SPLIT2F_LAYOUT = 1 if name == "direct" else 2
-            dev._Winv["split2f"] = ops[name]
         if sync:
             be.check(be.lib.gpk_set_option(be.h, b"k5_direct_sync", int(sync)))
-        dev.predict_var_dev(q, 1.1, 0.0, "float32", method)
+        dev.predict_var_dev(q, 1.1, 0.0, "float32", METHOD[name])
         dev.timing(True)
         for _ in range(reps):
-            v = dev.predict_var_dev(q, 1.1, 0.0, "float32", method)
+            v = dev.predict_var_dev(q, 1.1, 0.0, "float32", METHOD[name])
         ms = dev.kernel_times(_lib.GPK_TIMED_K5)
         dev.timing(False)
         err = float(((v.sqrt() - v64.sqrt()).abs() / v64.sqrt()).max())
         ref = v.clone() if ref is None else ref
+        per = {"split2": 3.0, "bf16x3": 6.0, "fp32": 1.0}[name]
         print(f"{form:12s}: kernel {np.mean(ms):8.2f} ms (min {np.min(ms):.2f} max {np.max(ms):.2f}) = "
-              f"{3.0 * N * N * M / np.mean(ms) / 1e9:7.1f} TF fp16 issued, {M / np.mean(ms):6.1f} k pred/s kernel-only; "
-              f"std err vs fp64 {err:.2e}; max |v - v(first)| {float((v - ref).abs().max()):.2e}", flush=True)
+              f"{float(N) * N * M / np.mean(ms) / 1e9:6.1f} TF fp32-equivalent, {per * N * N * M / np.mean(ms) / 1e9:7.1f} TF issued, "
+              f"{M / np.mean(ms):6.1f} k pred/s kernel-only; std err vs fp64 {err:.2e}; max |v - v(first)| {float((v - ref).abs().max()):.2e}",
+              flush=True)
+    be.check(be.lib.gpk_set_option(be.h, b"k5_direct_sync", 24))

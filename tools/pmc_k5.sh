@@ -1,8 +1,8 @@
 #!/bin/bash
-# Counter passes over the fp16 x 2 variance launches at the headline shape (tools/pmc_k5.sh [outdir] [FORMS]):
+# Counter passes over the variance launches at the headline shape (tools/pmc_k5.sh [outdir] [FORMS of tools/exp_k5_direct.py]):
 # clock / MFMA busy, wave wait breakdown, LDS and vector-memory instruction counts, L2 hit rate, fabric bytes.
 # One rocprofv3 --pmc run per counter set (never combined with the trace domains gpurun refuses).
-out=${1:-gpurun_out/pmc_k5}; forms=${2:-lds,direct:24}; mkdir -p $out
+out=${1:-gpurun_out/pmc_k5}; forms=${2:-split2:24,bf16x3}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -14,8 +14,7 @@ done
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]
-for pat, name in (("k5_split_kernel<4, 2, 4>", "fp16x2_lds_512x128"), ("k5_direct_kernel<4>", "fp16x2_direct_512x128"),
-                  ("k5_direct16_kernel", "fp16x2_direct16")):
+for pat, name in (("k5_direct_kernel<4>", "fp16x2_direct"), ("k5_split_kernel<4>", "bf16x3"), ("gemm_kernel<float, false, false, 1", "fp32_mfma")):
     acc = collections.OrderedDict(); dur = []
     for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True)):
         for r in csv.DictReader(open(f)):

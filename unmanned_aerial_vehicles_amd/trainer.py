@@ -233,6 +233,13 @@ class PreTrainedGP:
             except Exception as e:  # noqa: BLE001
                 print(f"GP model {name} could not be loaded: {e}")
                 models.pop(name, None)
+        if d["gp_models"] and not models:
+            # nothing survived the conversion: as in the reference, where a failed load leaves `is_loaded` False
+            # (`pretrained_gp.py:34-50`) and every prediction is the (0, 1e6) fallback
+            self.gp_models, self.scalers_X, self.scalers_y, self.training_stats = {}, {}, {}, {}
+            self._fused_bg = None
+            self.is_loaded = False
+            return False
         self.gp_models, self.scalers_X, self.scalers_y = models, sxs, sys_
         self.training_stats = d.get("training_stats", {})
         self._fused_bg = None
