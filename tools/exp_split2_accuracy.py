@@ -43,7 +43,8 @@ for (N, D, ls, sf2, noise, qscale) in cases:
         worst[m] = max(worst[m], e_ss)
         line += f" {m}: std {e_std:.1e} ss/kss {e_ss:.1e} |"
     if "split2" in dev._Winv:
-        line += f" scale {dev._Winv['split2'][1]:g}"
+        sc = dev._Winv["split2"][1]
+        line += f" row-block scales {float(sc.min()):g} .. {float(sc.max()):g}"
     print(line, flush=True)
     del dev
 print("worst |d ss| / kss:", {k: f"{v:.2e}" for k, v in worst.items()})

@@ -11,7 +11,7 @@ python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/prof.err
 cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv; rm -rf $out/prof
 python bench.py --workload c4 --steps 5 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 rc=$?"
-python bench.py --workload gram --steps 5 > $out/bench_gram.json 2> $out/bench_gram.err; echo "gram rc=$?"
+python bench.py --workload gram --steps 8 > $out/bench_gram.json 2> $out/bench_gram.err; echo "gram rc=$?"
 # the distributed code path (process group, RCCL all-gather) with the one rank this box has: started by the driver's
 # command line, and by bench.py's own launcher (parent -> torch.distributed.run -> rank)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "torchrun rc=$?"
