@@ -87,6 +87,89 @@ def test_composite_calls_against_oracle(N, D, P, M, ard):
         lib.gpk_destroy(h)
 
 
+@pytest.mark.parametrize("noise", [1e-3, 0.02])
+def test_composite_fp32_predict_is_gated(noise):
+    """gpk_predict(GPK_F32) applies the two fp32 serving gates itself: on a low-noise model, with training
+    points among the queries (variances far below the prior's), the fp32 request still meets mean 1e-4 / std 1e-3 against
+    the oracle - through the fp64 kernels for the whole model (noise 1e-3: the mean gate) or for the low-variance rows only
+    (noise 0.02).  The raw fp32 variance launch on the same queries (DeviceGP, gated=False) misses the bar on those rows."""
+    from unmanned_aerial_vehicles_amd import _lib
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
+    lib = _lib.load()
+    N, D, P, M = 3000, 9, 3, 1500
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+    Xq = np.ascontiguousarray(np.vstack([X[:600], rng.standard_normal((M - 600, D))]), dtype=np.float32)
+    ls, sf2, jitter = np.array([2.0]), 1.0, 1e-8
+    st = O.fit_fixed(X, Y, 2.0, sf2, noise, jitter, True)
+    om, os_ = O.predict(st, Xq.astype(np.float64), return_std=True)
+    h = C.c_void_p()
+    assert lib.gpk_create(C.byref(h), 0) == _lib.GPK_OK
+    try:
+        assert lib.gpk_set_stream(h, C.c_void_p(-1)) == _lib.GPK_OK
+        assert lib.gpk_fit(h, _dp(X), N, D, _dp(Y), P, _dp(ls), 1, sf2, noise, jitter, 1) == _lib.GPK_OK
+        m32, v32 = np.empty((M, P), dtype=np.float32), np.empty((M, P), dtype=np.float32)
+        assert lib.gpk_predict(h, Xq.ctypes.data_as(C.c_void_p), M, m32.ctypes.data_as(C.c_void_p),
+                               v32.ctypes.data_as(C.c_void_p), _lib.GPK_F32, 1) == _lib.GPK_OK, lib.gpk_last_error(h).decode()
+        e_m = np.max(np.abs(m32 - om.reshape(M, P))) / np.max(np.abs(om))
+        e_s = np.max(np.abs(np.sqrt(v32.astype(np.float64)) - os_.reshape(M, P)) / os_.reshape(M, P))
+        assert e_m < 1e-4 and e_s < 1e-3, (e_m, e_s)
+    finally:
+        lib.gpk_destroy(h)
+    # the same model through the raw fp32 kernels: the low variances at the training points are where they fail
+    dev = DeviceGP(X, st.Yn, get_backend(0))
+    dev.factorize(2.0, sf2, noise + jitter)
+    dev.solve_alpha()
+    kss = sf2 + noise
+    _, v_raw = dev.predict_gated_dev(Xq, st.y_mean, st.y_std, kss, 0.0, "float32", "auto", gated=False)
+    _, v_gat = dev.predict_gated_dev(Xq, st.y_mean, st.y_std, kss, 0.0, "float32", "auto", gated=True)
+    s_ref = os_.reshape(M, P)[:, 0] / st.y_std[0]
+    e_raw = np.max(np.abs(np.sqrt(v_raw.cpu().numpy()) - s_ref) / s_ref)
+    e_gat = np.max(np.abs(np.sqrt(v_gat.cpu().numpy()) - s_ref) / s_ref)
+    assert e_gat < 1e-3 and e_raw > e_gat, (e_raw, e_gat)
+
+
+def test_one_call_serving_step():
+    """gpk_predict_mean_var_split2 (K4 + K* in split form + the variance launch + un-normalise / pack / count in ONE C call)
+    against the separate launches and gpk_pack_mean_var: identical rows, and the count of rows below the re-check
+    threshold equals what the separate variance shows."""
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
+    be = get_backend(0)
+    N, D, P, M = 4096, 9, 3, 5000
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((N, D))
+    Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
+    ym, ys = Y.mean(0), Y.std(0)
+    dev = DeviceGP(X, (Y - ym) / ys, be)
+    dev.factorize(2.0, 1.0, 0.1001)
+    dev.solve_alpha()
+    Xq = np.vstack([X[:700], rng.standard_normal((M - 700, D))])
+    q = be.upload(Xq, torch.float32)
+    kss = 1.1
+    mean = dev.predict_mean_dev(q, ym, ys, "float32")
+    var = dev.predict_var_dev(q, kss, 0.0, "float32", "inverse_split2")
+    packed = be.empty((M, 2 * P), torch.float64)
+    be.check(be.lib.gpk_pack_mean_var(be.h, _lib.GPK_F32, C.c_void_p(mean.data_ptr()), C.c_void_p(var.data_ptr()), M, P,
+                                      _dp(np.ascontiguousarray(ys)), C.c_void_p(packed.data_ptr())))
+    want = var[:, None] * torch.as_tensor(ys ** 2, device=be.device)[None, :]
+    assert torch.equal(packed[:, :P], mean.double()) and float(((packed[:, P:] - want).abs() / want).max()) < 4e-16
+    one = dev.predict_packed_dev(q, ym, ys, kss, 0.0, "float32", "auto", gated=False)
+    assert torch.equal(one, packed)
+    # gated: the rows below the re-check fraction of the prior (raised here so that the training points among the queries
+    # fall under it) are recomputed in fp64, the others are untouched
+    assert dev.fp32_mean_ok()
+    dev.FP32_VAR_RECHECK_FRACTION = 0.12
+    gated = dev.predict_packed_dev(q, ym, ys, kss, 0.0, "float32", "auto", gated=True)
+    low = var < dev.FP32_VAR_RECHECK_FRACTION * kss
+    assert int(low.sum()) > 0 and torch.equal(gated[~low], packed[~low])
+    v64 = dev.predict_var_dev(q.double(), kss, 0.0, "float64", "inverse")
+    ys2 = torch.as_tensor(ys ** 2, device=be.device)
+    assert float(((gated[low][:, P:] - v64[low][:, None] * ys2[None, :]).abs() / (v64[low][:, None] * ys2[None, :])).max()) < 1e-9
+
+
 @pytest.mark.parametrize("N,D,B,ard", [(301, 10, 6, True), (1500, 9, 3, True), (640, 4, 2, False), (130, 16, 8, True)])
 def test_batched_composite_calls_against_oracle(N, D, B, ard):
     """gpk_fit_batched / gpk_predict_batched / gpk_lml_batched: B per-axis models with their own hyper-parameters on
