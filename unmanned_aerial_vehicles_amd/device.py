@@ -478,8 +478,9 @@ class DeviceGP:
     # term k*_j alpha_j of the mean is off by a few 1e-7 of itself, with random sign: the mean error is
     # c * sqrt(sum_j (k*_j alpha_j)^2) with c = 2.1e-7 .. 3.8e-7 for the matrix-core kernel and 3.1e-7 .. 8.9e-7 for the
     # exact-difference kernel (worst query of a batch of <= 2000, measured over 41 random models, N = 431 .. 65 536,
-    # D = 1 .. 16, noise 1e-3 .. 0.3: tools/exp_fp32_gate.py, profiles/r02_fp32_gate_calibration.log; the fp32
-    # rounding of the inputs themselves accounts for about half of it).  Fine for the models the reference trains
+    # D = 1 .. 16, noise 1e-3 .. 0.3: tools/exp_fp32_gate.py, profiles/r02_fp32_gate_calibration.log and, with round 3's
+    # kernels, r03_fp32_gate_calibration.log; the fp32 rounding of the inputs themselves accounts for about half of it;
+    # the constants below are upper bounds of that wherever the amplification is >= 10).  Fine for the models the reference trains
     # (noise 0.03 - 0.3), not for sf2 N / noise ~ 1e7, where alpha is huge and cancels.  `fp32_mean_amplification`
     # measures A2 = max_m sqrt(sum_j (k_mj alpha_j)^2) / max_m |mean_m| on a sample of training rows (where it is
     # largest) once per alpha; the estimator routes a model with c * A2 above 1e-4 to the fp64 kernels (gpr.py).
