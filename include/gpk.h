@@ -68,12 +68,12 @@ GPK_API int64_t gpk_padded(int64_t n);
  * launches with that tag still in the ring, oldest first (*n_out of them, at most max_n).  bench.py uses it to
  * report the dominant kernel's duration over exactly the timed steps; rocprofv3's kernel trace of the same run is
  * the cross-check.  No reference counterpart (the reference has no instrumentation on this path).        */
-/* gpk_set_option: the tuning knobs a fresh handle reads from the environment (GPK_K5_SPLIT2_TILE, GPK_K5_DIRECT_SYNC,
- * GPK_K5_SUPER, GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle:
+/* gpk_set_option: the tuning knobs a fresh handle reads from the environment (GPK_K5_SPLIT2_TILE, GPK_K5_SUPER,
+ * GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle:
  * "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = the tallest of the 512 / 256 / 128 x 128 tiles that still comes in at
- * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_direct_sync" (that launch: a workgroup
- * barrier every so many k-tiles, 0 = never), "k5_super", "small_path", "trsm256", "trtri_levels", "gemm_small_tiles",
- * "k3_stream_min_np".  Used by the A/B timings and by the tests that pin a fast path to its plain form.            */
+ * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256",
+ * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np".  Used by the A/B timings and by the tests that pin a fast path
+ * to its plain form.                                                                                                */
 GPK_API int gpk_set_option(gpk_handle h, const char* name, int value);
 enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2 };
 GPK_API int gpk_timing(gpk_handle h, int enable);

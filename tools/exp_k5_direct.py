@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The variance launch (K5) at the headline shape, form by form, on one box: `split2[:n]` = the fp16 x 2 launch with its
-operands going from L2 straight into registers (the fp32 serving default; n = workgroup barrier every n k-tiles),
+operands going from L2 straight into registers (the fp32 serving default),
 `bf16x3` = the exact three-way bf16 split (LDS-staged), `fp32` = the exact-fp32 MFMA GEMM.  Kernel time from the
 library's own event brackets, agreement with the first form, error against the fp64 kernels.  With SWEEP=1 (default) a
 correctness sweep over small shapes first: every tile height of the fp16 x 2 launch, ragged N and M, a low-noise model.
@@ -55,7 +55,7 @@ if os.environ.get("HEADLINE", "1") == "1":
     dev = model(N)
     q = queries(M)
     v64 = dev.predict_var_dev(q.double(), 1.1, 0.0, "float64", "inverse")
-    forms = os.environ.get("FORMS", "split2:24,split2:0,bf16x3,fp32,split2:24").split(",")
+    forms = os.environ.get("FORMS", "split2,bf16x3,fp32,split2").split(",")
     names = {f.partition(":")[0] for f in forms}
     dev.inverse_factor(True)
     dev._Winv.pop("f64", None)
@@ -68,8 +68,6 @@ if os.environ.get("HEADLINE", "1") == "1":
     ref = None
     for form in forms:
         name, _, sync = form.partition(":")
-        if sync:
-            be.check(be.lib.gpk_set_option(be.h, b"k5_direct_sync", int(sync)))
         dev.predict_var_dev(q, 1.1, 0.0, "float32", METHOD[name])
         dev.timing(True)
         for _ in range(reps):
@@ -83,4 +81,3 @@ if os.environ.get("HEADLINE", "1") == "1":
               f"{float(N) * N * M / np.mean(ms) / 1e9:6.1f} TF fp32-equivalent, {per * N * N * M / np.mean(ms) / 1e9:7.1f} TF issued, "
               f"{M / np.mean(ms):6.1f} k pred/s kernel-only; std err vs fp64 {err:.2e}; max |v - v(first)| {float((v - ref).abs().max()):.2e}",
               flush=True)
-    be.check(be.lib.gpk_set_option(be.h, b"k5_direct_sync", 24))

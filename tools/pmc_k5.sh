@@ -2,7 +2,7 @@
 # Counter passes over the variance launches at the headline shape (tools/pmc_k5.sh [outdir] [FORMS of tools/exp_k5_direct.py]):
 # clock / MFMA busy, wave wait breakdown, LDS and vector-memory instruction counts, L2 hit rate, fabric bytes.
 # One rocprofv3 --pmc run per counter set (never combined with the trace domains gpurun refuses).
-out=${1:-gpurun_out/pmc_k5}; forms=${2:-split2:24,bf16x3}; mkdir -p $out
+out=${1:-gpurun_out/pmc_k5}; forms=${2:-split2,bf16x3}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \

@@ -49,5 +49,5 @@ PY
 rm -rf $out/prof $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 [ "$ONLY_TRAFFIC" = "1" ] && exit 0      # steps 1 and 2 only
 # 3. clock / MFMA busy / waits / L2 hit rate of the variance launches (tools/pmc_k5.sh -> pmc_k5_<form>.txt)
-bash tools/pmc_k5.sh $out/k5 split2:24,bf16x3,fp32
+bash tools/pmc_k5.sh $out/k5 split2,bf16x3,fp32
 cp $out/k5/pmc_k5_*.txt $out/ 2>/dev/null

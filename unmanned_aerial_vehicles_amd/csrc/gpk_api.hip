@@ -30,7 +30,6 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
   if (const char* e = getenv("GPK_K5_SUPER")) h->k5_super = atoi(e);
   if (const char* e = getenv("GPK_K5_SPLIT2_TILE")) { const int v = atoi(e); h->k5_split2_tile = (v >= 0 && v <= 2) ? v : 0; }
-  if (const char* e = getenv("GPK_K5_DIRECT_SYNC")) h->k5_direct_sync = atoi(e);
   if (const char* e = getenv("GPK_SMALL_PATH")) h->small_path = atoi(e);
   if (const char* e = getenv("GPK_TRSM256")) h->trsm256 = atoi(e);
   if (const char* e = getenv("GPK_TRTRI_LEVELS")) h->trtri_levels = atoi(e);
@@ -81,7 +80,6 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   GPK_REQUIRE(h, name, "set_option: null name");
   const std::string n(name);
   if (n == "k5_split2_tile") h->k5_split2_tile = (value >= 0 && value <= 2) ? value : 0;
-  else if (n == "k5_direct_sync") h->k5_direct_sync = value;
   else if (n == "k5_super") h->k5_super = value;
   else if (n == "small_path") h->small_path = value;
   else if (n == "trsm256") h->trsm256 = value;

@@ -43,7 +43,6 @@ struct gpk_context {
   int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
   int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
                              // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
-  int k5_direct_sync = 24;   // k5_direct_kernel: workgroup barrier every this many k-tiles (GPK_K5_DIRECT_SYNC; 0: never)
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // gpk_timing: HIP-event brackets around the dominant launches (K5 variance GEMM, K1 Gram kernel), a ring of pairs

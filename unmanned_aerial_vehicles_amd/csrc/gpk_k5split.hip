@@ -274,7 +274,8 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
 // 32 AB w .. of the tile and ALL 128 columns (AB x 4 accumulator blocks of 32 x 32: 256 registers at AB = 4).  A row
 // block of W is used by one wave only, so nothing is gained by staging it in LDS: each wave loads its own A fragments
 // straight into registers (they come from L2 exactly once per workgroup, as before) and the four waves' identical B
-// (K*) fragment loads meet in the CU's vector L1.  Per k16 step and workgroup: 40 KiB from L2 as before, but no LDS
+// (K*) fragment loads meet in the CU's vector L1 (a barrier every few k-tiles to keep them together measured the same as
+// none: there is none).  Per k16 step and workgroup: 40 KiB from L2 as before, but no LDS
 // writes (40 KiB before) and no LDS reads (96 KiB before), no barriers, half the fragment bytes per MFMA (0.33
 // fragment loads per MFMA against 0.5).  The launch is bound by the clock the chip holds under this load
 // (profiles/r02_pmc_mfma_k5_fp16x2.txt: MFMA busy 0.89 at 1.39 GHz): less data movement per product is what raises it.
@@ -289,15 +290,17 @@ struct DParams {
   long long Mp;
   float kscale;         // the scale of K*
   int ntm, ntn, nst;    // 128-row tile rows, 128-column tile columns, super-tiles
-  int sync_every;       // a workgroup barrier every this many k-tiles keeps the four waves' B loads together in L1 (0: never)
 };
 
 template <int AB>
 __global__ __launch_bounds__(256, 1) void k5_direct_kernel(DParams p) {
   constexpr int TMR = 128 * AB, GSZ = 32, BH = 1024 / TMR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- tile mapping (as k5_split_kernel): bands of 1024 rows walked column by column in groups of 32 tiles, serpentine
-  // over the XCDs, heavy rows first, lockstep k-ranges inside a group
+  // ---- tile mapping: bands of 1024 rows walked column by column in groups of 32 tiles (one group = the resident
+  // workgroups of an XCD: 2 x 512 rows of W and 16 x 128 queries shared through its L2), serpentine over the XCDs, heavy
+  // rows first.  Every tile runs over its OWN k-range: the lockstep union of k_ranges that the LDS-staged kernels use costs
+  // 0.8 % more MFMA work and measured 0.6 % slower here; bands of 2048 / 4096 rows (all XCDs on one W band, sharing it
+  // through the Infinity Cache) measured 2 % / 15 % slower - what the XCD's own L2 misses costs more than HBM saves.
   const int ntm = p.ntm * 128 / TMR;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int grp = j / GSZ, slot = j - grp * GSZ;
@@ -313,11 +316,11 @@ __global__ __launch_bounds__(256, 1) void k5_direct_kernel(DParams p) {
     tn = idx / hh;
     tm = band * BH + (idx - tn * hh);
   }
-  const int band0 = min(st * GSZ / per, nfull), band1 = min(min(st * GSZ + GSZ - 1, total - 1) / per, nfull);
   tm = ntm - 1 - tm;
-  const int rhi = (band1 - band0 <= 1) ? ntm - 1 - band0 * BH : tm;
-  const int nkt = (rhi + 1) * (TMR / 16);          // k-tiles of 16 (a multiple of 8)
   const int row0 = tm * TMR, col0 = tn * 128;
+  // k-tiles of 16 of THIS WAVE: W is lower triangular, so its rows row0 + 32 AB wave .. end at column row0 + 32 AB (wave + 1)
+  // (the waves of a workgroup do not wait for each other before the epilogue)
+  const int nkt = (row0 + 32 * AB * (wave + 1)) / 16;
 
   f16v acc[AB][4];
 #pragma unroll
@@ -373,12 +376,11 @@ __global__ __launch_bounds__(256, 1) void k5_direct_kernel(DParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  int kt = 0, since = 0;
+  int kt = 0;
   for (; kt + 3 <= nkt; kt += 3) {
     body(kt, IntC<0>{});
     body(kt + 1, IntC<1>{});
     body(kt + 2, IntC<2>{});
-    if (p.sync_every > 0 && (since += 3) >= p.sync_every) { since = 0; __builtin_amdgcn_s_barrier(); }
   }
   if (kt < nkt) {
     body(kt, IntC<0>{});
@@ -518,7 +520,6 @@ int split2_launch(gpk_handle h, const char* who, const float* X, int64_t N, int 
   p.kscale = (float)k_scale;
   p.ntm = ntm; p.ntn = ntn;
   p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
-  p.sync_every = h->k5_direct_sync;
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
   gpk_time_begin(h, GPK_TIMED_K5);
   if (ab == 4) hipLaunchKernelGGL(k5_direct_kernel<4>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
