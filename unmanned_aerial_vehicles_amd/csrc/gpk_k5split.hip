@@ -290,6 +290,7 @@ struct DParams {
   long long Mp;
   float kscale;         // the scale of K*
   int ntm, ntn, nst;    // 128-row tile rows, 128-column tile columns, super-tiles
+  int per_pad;          // tile slots per band of the walk (>= band height in tiles x ntn)
 };
 
 template <int AB>
@@ -306,13 +307,15 @@ __global__ __launch_bounds__(256, 1) void k5_direct_kernel(DParams p) {
   const int grp = j / GSZ, slot = j - grp * GSZ;
   const int st = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
   if (st >= p.nst) return;
-  const int per = BH * p.ntn, nfull = ntm / BH, hlast = ntm - nfull * BH, total = ntm * p.ntn;
+  // (p.per_pad: the BH x ntn tiles of a band rounded up to whole groups when that idles few slots - every group is then
+  // 2 tile rows x 16 columns of ONE band instead of straddling two bands, i.e. 3072 instead of up to 4096 operand rows)
+  const int nfull = ntm / BH, hlast = ntm - nfull * BH;
   const int t = st * GSZ + slot;
-  if (t >= total) return;
   int tm, tn;
   {
-    const int band = min(t / per, nfull);
-    const int idx = t - band * per, hh = band < nfull ? BH : hlast;
+    const int band = min(t / p.per_pad, nfull);
+    const int idx = t - band * p.per_pad, hh = band < nfull ? BH : hlast;
+    if (idx >= hh * p.ntn) return;               // a padding slot, or beyond the last tile
     tn = idx / hh;
     tm = band * BH + (idx - tn * hh);
   }
@@ -519,7 +522,14 @@ int split2_launch(gpk_handle h, const char* who, const float* X, int64_t N, int 
   p.Mp = Mp;
   p.kscale = (float)k_scale;
   p.ntm = ntm; p.ntn = ntn;
-  p.nst = (int)(((long long)ntmT * ntn + gsz - 1) / gsz);
+  {
+    // the tile walk: bands of 1024 rows; a band's tiles are rounded up to whole groups of 32 when that idles at most an
+    // eighth of the slots (headline shape: 158 -> 160)
+    const int bh = 1024 / (128 * ab), per = bh * ntn, pad = (per + gsz - 1) / gsz * gsz;
+    p.per_pad = (pad - per) * 8 <= per ? pad : per;
+    const int nfull = ntmT / bh, hlast = ntmT - nfull * bh;
+    p.nst = (int)(((long long)nfull * p.per_pad + (long long)hlast * ntn + gsz - 1) / gsz);
+  }
   const long long nblocks = (long long)((p.nst + 7) / 8) * 8 * gsz;
   gpk_time_begin(h, GPK_TIMED_K5);
   if (ab == 4) hipLaunchKernelGGL(k5_direct_kernel<4>, dim3((unsigned)nblocks), dim3(256), 0, h->stream, p);
