@@ -316,13 +316,14 @@ __global__ __launch_bounds__(256) void cross_t_kernel(const T* __restrict__ X, l
 // contiguous output.
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+constexpr int CS2_QS = 4;
 template <int DD>   // DD = D (query coordinates in registers; one instantiation per feature count)
 __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restrict__ Xq, long long M,
                                                            const float* __restrict__ X, long long N, int D, LsArr ls,
                                                            float sf2, float scale, u4_t* __restrict__ dst, long long Np) {
   __shared__ __attribute__((aligned(16))) float xs[DD][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long j0 = (long long)blockIdx.x * 128, q0 = (long long)blockIdx.y * 64;
+  const long long j0 = (long long)blockIdx.x * 128;
   for (int e = tid; e < 128 * DD; e += 256) {
     const int d = e >> 7, i = e & 127;
     const long long gj = j0 + i;
@@ -330,12 +331,17 @@ __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restri
   }
   __syncthreads();
   const int r = lane & 31, hh = lane >> 5;
-  // two query blocks of 32 per workgroup; a wave takes four of the eight k16 blocks of one of them
+  const long long KB = Np >> 4, Mp = (M + 127) / 128 * 128;
+  // CS2_QS sub-blocks of 64 queries per workgroup (the staged points serve 256 queries): two query blocks of 32 per
+  // sub-block; a wave takes four of the eight k16 blocks of one of them
+#pragma unroll 1
+  for (int qs = 0; qs < CS2_QS; ++qs) {
+  const long long q0 = ((long long)blockIdx.y * CS2_QS + qs) * 64;
+  if (q0 >= Mp) break;
   const long long qblk = (q0 >> 5) + (wave >> 1), q = qblk * 32 + r;
   float xq[DD];
 #pragma unroll
   for (int d = 0; d < DD; ++d) xq[d] = (q < M ? Xq[q * DD + d] : 0.f) / (float)ls.v[d];
-  const long long KB = Np >> 4;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int kb = 4 * (wave & 1) + t, kbase = 16 * kb + 8 * hh;
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(256) void cross_split2_kernel(const float* __restri
     u4_t* o = dst + ((qblk * KB + (j0 >> 4) + kb) * 2) * 64 + lane;
     o[0] = __builtin_bit_cast(u4_t, p0);
     o[64] = __builtin_bit_cast(u4_t, p1);
+  }
   }
 }
 
@@ -742,7 +749,7 @@ int gpk_cross_split2(gpk_handle h, const float* Xq, int64_t M, const float* X, i
   LsArr l;
   GPK_TRY(fill_ls(h, ls, D, l));
   GPK_REQUIRE(h, Mp / 64 < 65536, "cross_split2: at most 2^22 queries per call");
-  const dim3 grid((unsigned)(Np / 128), (unsigned)(Mp / 64));
+  const dim3 grid((unsigned)(Np / 128), (unsigned)((Mp / 64 + CS2_QS - 1) / CS2_QS));
 #define GPK_CS2(DD) case DD: hipLaunchKernelGGL(cross_split2_kernel<DD>, grid, dim3(256), 0, h->stream, Xq, (long long)M, X, (long long)N, D, \
                                                 l, (float)sf2, (float)scale, (u4_t*)dst, (long long)Np); break
   switch (D) {
