@@ -345,7 +345,11 @@ GPK_API int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const 
  *   called at src/px4/simple_gp.py:170-177; GaussianProcess.fit, gaussian_process.py:173-201.
  * gpk_predict: Xq host (M x D), mean host (M x P), var host (M x P: per-output VARIANCE, already multiplied by
  *   y_std^2; NULL = means only), all of `dtype` (GPK_F64: double buffers, fp64 kernels; GPK_F32: float buffers, the
- *   fp32 serving kernels - matrix-core mean when admissible, fp16 x 2 split variance).  var_includes_noise != 0:
+ *   fp32 serving kernels - matrix-core mean when admissible, fp16 x 2 split variance - behind the two fp32 serving
+ *   gates: a model whose fp32 mean would leave 1e-4 (estimated once per model from two fp64 launches on <= 1024 training
+ *   rows) is served by the fp64 kernels, and rows whose fp32 variance is below 1 % of the prior's are recomputed by the
+ *   fp64 launch; GPK_F32 is a request for speed, the stated bars - mean 1e-4, std 1e-3 - hold either way).
+ *   var_includes_noise != 0:
  *   k** = sf2 + noise, variance clipped at 0 (scikit-learn: Sum.diag, _gpr.py:474-485; take sqrt for its std);
  *   == 0: k** = sf2, floored at 1e-10 (gaussian_process.py:229-233).  Queries are processed in panels.
  *   Replaces: GaussianProcessRegressor.predict, _gpr.py:441-494 (src/px4/simple_gp.py:194, mpc.py:1490-1506);
