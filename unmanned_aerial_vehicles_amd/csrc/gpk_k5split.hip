@@ -264,8 +264,8 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
   }
 }
 
-// ---- third form of the fp16 x 2 launch: operands straight from L2 into MFMA fragments, no LDS ------------------------
-// "Fragment order" of a split operand (layout 1): the 16-byte chunk (row, k16 block kb, half h, part s) lives at chunk
+// ---- the fp16 x 2 launch: operands straight from L2 into MFMA fragments, no LDS ------------------------------------
+// "Fragment order" of a split operand: the 16-byte chunk (row, k16 block kb, half h, part s) lives at chunk
 // index (((row / 32) * KB + kb) * 2 + s) * 64 + h * 32 + row % 32 (KB = cols / 16): the 64 chunks of one
 // (32-row block, k16 block, part) - exactly one v_mfma_f32_32x32x16_f16 operand, lane = h * 32 + row % 32 - are 1 KiB
 // of contiguous memory, so a fragment is ONE fully coalesced buffer_load_dwordx4 per wave (eight whole 128-byte lines),
@@ -273,12 +273,13 @@ __global__ __launch_bounds__(WR * 128, 2) void k5_split_kernel(SParams p) {
 // The launch: tiles of (128 AB) x 128, four waves, one per SIMD with the whole 512-register file; wave w owns rows
 // 32 AB w .. of the tile and ALL 128 columns (AB x 4 accumulator blocks of 32 x 32: 256 registers at AB = 4).  A row
 // block of W is used by one wave only, so nothing is gained by staging it in LDS: each wave loads its own A fragments
-// straight into registers (they come from L2 exactly once per workgroup, as before) and the four waves' identical B
+// straight into registers (they come from L2 exactly once per workgroup, as in the LDS-staged kernel of round 2) and the four waves' identical B
 // (K*) fragment loads meet in the CU's vector L1 (a barrier every few k-tiles to keep them together measured the same as
-// none: there is none).  Per k16 step and workgroup: 40 KiB from L2 as before, but no LDS
-// writes (40 KiB before) and no LDS reads (96 KiB before), no barriers, half the fragment bytes per MFMA (0.33
-// fragment loads per MFMA against 0.5).  The launch is bound by the clock the chip holds under this load
-// (profiles/r02_pmc_mfma_k5_fp16x2.txt: MFMA busy 0.89 at 1.39 GHz): less data movement per product is what raises it.
+// none: there is none).  Per k16 step and workgroup: 40 KiB from L2 as in that kernel, but no LDS writes (40 KiB there)
+// and no LDS reads (96 KiB there), no barriers, and 0.33 fragment loads per MFMA against 0.5.  The launch is bound by the
+// clock the chip holds under this load (that kernel: MFMA busy 0.89 at 1.39 GHz, profiles/r02_pmc_mfma_k5_fp16x2.txt; this
+// one: 0.92 at 1.42 GHz with 8 % less time, profiles/r03_pmc_k5_fp16x2_direct.txt): less data movement per product is what
+// raises it.
 // A ring of three k-tiles of fragments (3 x 64 registers) keeps two k-tiles in flight; a fragment's registers are
 // refilled (k-tile kt + 3) right behind the last MFMA that reads them.
 struct DParams {
