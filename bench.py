@@ -72,24 +72,32 @@ def parse_args(argv=None):
 
 def launch_ranks(args):
     """Plain `python bench.py --gpus N` with N > 1: start the ranks as a child torch.distributed.run job.  Nothing in
-    this process has imported torch or touched the GPU."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    this process has imported torch or touched the GPU.  The rendezvous port is found by bind-and-close, which leaves a
+    window in which another process can take it: a child that fails within a minute without a result line is started
+    again on a fresh port (twice at most)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required by RCCL on this host driver
     env["BENCH_LAUNCHED_BY_PARENT"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    lines = []
-    for ln in p.stdout:                       # rank 0 prints exactly one JSON line; anything else goes to stderr
-        if ln.lstrip().startswith('{"metric"'):
-            lines.append(ln.strip())
-        else:
-            sys.stderr.write(ln)
-    rc = p.wait()
+    rc, lines = 1, []
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.perf_counter()
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+        lines = []
+        for ln in p.stdout:                       # rank 0 prints exactly one JSON line; anything else goes to stderr
+            if ln.lstrip().startswith('{"metric"'):
+                lines.append(ln.strip())
+            else:
+                sys.stderr.write(ln)
+        rc = p.wait()
+        if rc == 0 or lines or time.perf_counter() - t0 > 60.0:
+            break
+        sys.stderr.write(f"bench.py: the ranks failed after {time.perf_counter() - t0:.0f} s (rc {rc}); starting them again on a new port\n")
     if lines:
         print(lines[-1], flush=True)
     if rc == 0 and not lines:
