@@ -361,7 +361,8 @@ def main():
     if use_w:
         # the inverse factor (34 GB) and its scratch come from torch's caching allocator: map them once outside the
         # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
-        warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64)]
+        warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64),
+                be.empty((dev.Np, dev.Np), torch.float32), be.empty((dev.Np * dev.Np * 4,), torch.uint8)]
         del warm
         torch.cuda.synchronize()
     t0 = time.perf_counter()
