@@ -130,7 +130,8 @@ def test_composite_fp32_predict_is_gated(noise):
     assert e_gat < 1e-3 and e_raw > e_gat, (e_raw, e_gat)
 
 
-def test_one_call_serving_step():
+@pytest.mark.parametrize("M", [5000, 20000])        # 20 000 queries: two trips through the 16 384-query panel loop
+def test_one_call_serving_step(M):
     """gpk_predict_mean_var_split2 (K4 + K* in split form + the variance launch + un-normalise / pack / count in ONE C call)
     against the separate launches and gpk_pack_mean_var: identical rows, and the count of rows below the re-check
     threshold equals what the separate variance shows."""
@@ -138,7 +139,7 @@ def test_one_call_serving_step():
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
     be = get_backend(0)
-    N, D, P, M = 4096, 9, 3, 5000
+    N, D, P = 4096, 9, 3
     rng = np.random.default_rng(3)
     X = rng.standard_normal((N, D))
     Y = np.sin(X @ rng.standard_normal((D, P))) + 0.1 * rng.standard_normal((N, P))
