@@ -713,13 +713,11 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
   const int64_t nt = Np / TS;
   const int64_t tiles = nt * (nt + 1) / 2;
   GPK_REQUIRE(h, tiles < (1ll << 31), "gram: N too large");
-  bool stream_nt = Np >= 16384;   // streaming stores once K exceeds the caches
-  if (const char* e = getenv("GPK_GRAM_NT")) stream_nt = (e[0] == '1');   // tuning override
+  const bool stream_nt = Np >= 16384;   // streaming stores once K exceeds the caches
   GPK_REQUIRE(h, ((uintptr_t)K % 16) == 0, "gram: K must be 16-byte aligned");
   const dim3 block(256);
   // strip kernel for D <= 16 (one chunk of features); the tile-per-workgroup kernel otherwise
-  bool strip = D <= DCH;
-  if (const char* e = getenv("GPK_GRAM_STRIP")) strip = strip && (e[0] == '1');
+  const bool strip = D <= DCH;
   long long nstrips = 0;
   for (long long r = 0; r < nt; ++r) nstrips += r / GS + 1;
   const dim3 grid((unsigned)(strip ? nstrips : tiles));
