@@ -267,14 +267,57 @@ __device__ __forceinline__ void consume(const f16v& cur, const float (&av)[PP], 
   }
 }
 
-// D <= 14 (operand depth D + 2 <= 16).  LDS image of a staged point block (32 points): [part][half][point] x 16 B.
+// D <= 14 (operand depth D + 2 <= 16).  The training side of the product is the same for every query block, so it is
+// prepared ONCE per call by mean_prep_kernel - centred, scaled, split, in MFMA-fragment order: block of 32 points jb,
+// part s, half h, point t at xb[((jb * 3 + s) * 2 + h) * 32 + t], i.e. one fully coalesced 16-byte load per lane and
+// part - and the waves load their B fragments from L2 straight into registers: no LDS, no barriers.  (Staging and
+// splitting 512 points per round inside every workgroup, as this kernel did before, was a third of its vector-ALU
+// instructions: every workgroup of 256 queries redid the split of the whole training chunk.)
+// alpha goes along as al[(jb * PP + p) * 32 + t] (zero beyond N: padded points then contribute exp2(0) * 0).
+template <int PP>
+__global__ __launch_bounds__(256) void mean_prep_kernel(const float* __restrict__ X, const float* __restrict__ alpha,
+                                                        long long N, int D, F16 sc, F16 ctr, u32x4* __restrict__ xb,
+                                                        float* __restrict__ al, long long npad) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= npad) return;
+  const bool in = j < N;
+  float v[16];
+  float tn = 0.f;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    float u = 0.f;
+    if (d < D && in) u = (X[j * D + d] - ctr.v[d]) * sc.v[d];
+    tn = __builtin_fmaf(u, u, tn);
+    v[d] = -2.f * u;
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    if (d == D) v[d] = tn;
+    if (d == D + 1) v[d] = in ? 1.f : 0.f;      // multiplies the queries' |u_q|^2 component
+  }
+  const long long jb = j >> 5;
+  const int t = (int)(j & 31);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float vh[8];
+#pragma unroll
+    for (int j8 = 0; j8 < 8; ++j8) vh[j8] = v[8 * h + j8];
+    u32x4 f[3];
+    split_frag(vh, f);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) xb[((jb * 3 + s3) * 2 + h) * 32 + t] = f[s3];
+  }
+#pragma unroll
+  for (int p = 0; p < PP; ++p) al[(jb * PP + p) * 32 + t] = in ? alpha[j * PP + p] : 0.f;
+}
+
+template <int PP> struct MeanOperand { u32x4 bf[3]; float av[PP]; };
+
 template <int PP, int QB>
-__global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restrict__ X, const float* __restrict__ alpha,
-                                                           long long N, int D, F16 sc, F16 ctr,
-                                                           const float* __restrict__ Xq, long long M, long long chunk,
+__global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const u32x4* __restrict__ xb, const float* __restrict__ al,
+                                                           int nblk, int D, F16 sc, F16 ctr,
+                                                           const float* __restrict__ Xq, long long M, int chunk_blocks,
                                                            float* __restrict__ partial) {
-  __shared__ u32x4 xb[MM_TJ / 32][3][2][32];
-  __shared__ float al[PP][MM_TJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, lh = lane >> 5;
   const long long q0 = (long long)blockIdx.x * (128 * QB);
@@ -303,11 +346,9 @@ __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restri
     }
     split_frag(v, a[b]);
   }
-  f16v seed[QB];                      // the chains start from zero
+  f16v zero;                          // the chains start from zero
 #pragma unroll
-  for (int b = 0; b < QB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) seed[b][r] = 0.f;
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 
   f2 acc[QB][8][PP];
 #pragma unroll
@@ -317,73 +358,47 @@ __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const float* __restri
 #pragma unroll
       for (int p = 0; p < PP; ++p) acc[b][i][p] = f2{0.f, 0.f};
 
-  const long long n0 = (long long)blockIdx.y * chunk;
-  const long long n1 = min(N, n0 + chunk);
-  for (long long jb = n0; jb < n1; jb += MM_TJ) {
-    __syncthreads();
-    // ---- stage: point t -> components [-2 u (D) | |u|^2 | 0 ...] (16), split, as two 8-wide halves
-    for (int t = tid; t < MM_TJ; t += 256) {
-      const long long j = jb + t;
-      const bool in = j < n1;
-      float v[16];
-      float tn = 0.f;
+  // this workgroup's chunk of point blocks; two operands in registers: the one in use and the next, whose loads are
+  // issued a whole step (12 MFMAs, 32 exponentials) ahead of their first use
+  const int b0 = blockIdx.y * chunk_blocks, b1 = min(nblk, b0 + chunk_blocks), nb = b1 - b0;
+  MeanOperand<PP> R[2];
+  auto ldf = [&](int blk, MeanOperand<PP>& o) {
+    blk = min(blk, b1 - 1);
+    const u32x4* q = xb + (long long)blk * 192 + lh * 32 + ln;
+    o.bf[0] = q[0]; o.bf[1] = q[64]; o.bf[2] = q[128];
+  };
+  auto lda = [&](int blk, MeanOperand<PP>& o) {
+    blk = min(blk, b1 - 1);
 #pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        float u = 0.f;
-        if (d < D && in) u = (X[j * D + d] - ctr.v[d]) * sc.v[d];
-        tn = __builtin_fmaf(u, u, tn);
-        v[d] = -2.f * u;
-      }
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        if (d == D) v[d] = tn;
-        if (d == D + 1) v[d] = in ? 1.f : 0.f;      // multiplies the queries' |u_q|^2 component
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float vh[8];
-#pragma unroll
-        for (int j8 = 0; j8 < 8; ++j8) vh[j8] = v[8 * h + j8];
-        u32x4 f[3];
-        split_frag(vh, f);
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) xb[t >> 5][s3][h][t & 31] = f[s3];
-      }
-#pragma unroll
-      for (int p = 0; p < PP; ++p) al[p][t] = in ? alpha[j * PP + p] : 0.f;
-    }
-    __syncthreads();
-    const int nblk = (int)((min((long long)MM_TJ, n1 - jb) + 31) / 32);
-
-    u32x4 bf[3];
+    for (int p = 0; p < PP; ++p) o.av[p] = al[((long long)blk * PP + p) * 32 + ln];
+  };
+  ldf(b0, R[0]); lda(b0, R[0]);
+  ldf(b0 + 1, R[1]); lda(b0 + 1, R[1]);
+  f16v cur = chain6(a[0], R[0].bf, zero);
+  // one step = the point block in `c` against the wave's QB query blocks; the chain of the next product is issued before
+  // the finished one is turned into kernel values (MFMAs and vector work of one wave overlap)
+  auto step = [&](int jj, MeanOperand<PP>& c, const MeanOperand<PP>& n) {
     float av[PP];
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) bf[s3] = xb[0][s3][lh][ln];
-#pragma unroll
-    for (int p = 0; p < PP; ++p) av[p] = al[p][ln];
-    f16v cur = chain6(a[0], bf, seed[0]);
-    for (int jj = 0; jj < nblk; ++jj) {
-      const int jn = min(jj + 1, nblk - 1);
-      u32x4 bfn[3];
-      float avn[PP];
-#pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) bfn[s3] = xb[jn][s3][lh][ln];
-#pragma unroll
-      for (int p = 0; p < PP; ++p) avn[p] = al[p][jn * 32 + ln];
-      if constexpr (QB == 2) {
-        const f16v nxt = chain6(a[1], bf, seed[1]);
-        consume<PP>(cur, av, acc[0]);
-        cur = nxt;
-      }
-      const f16v nxt = chain6(a[0], bfn, seed[0]);     // (discarded after the last block)
-      consume<PP>(cur, av, acc[QB - 1]);
+    for (int p = 0; p < PP; ++p) av[p] = c.av[p];
+    if constexpr (QB == 2) {
+      const f16v nxt = chain6(a[1], c.bf, zero);
+      ldf(b0 + jj + 2, c);                              // the fragments of c have had their last use
+      consume<PP>(cur, av, acc[0]);
       cur = nxt;
-#pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) bf[s3] = bfn[s3];
-#pragma unroll
-      for (int p = 0; p < PP; ++p) av[p] = avn[p];
     }
+    const f16v nxt = chain6(a[0], n.bf, zero);          // (discarded after the last block)
+    if constexpr (QB == 1) ldf(b0 + jj + 2, c);
+    consume<PP>(cur, av, acc[QB - 1]);
+    cur = nxt;
+    lda(b0 + jj + 2, c);
+  };
+  int jj = 0;
+  for (; jj + 2 <= nb; jj += 2) {
+    step(jj, R[0], R[1]);
+    step(jj + 1, R[1], R[0]);
   }
+  if (jj < nb) step(jj, R[0], R[1]);
 
 #pragma unroll
   for (int b = 0; b < QB; ++b)
@@ -433,7 +448,9 @@ mm_fn mm_pick_p(int P) {
     default: return mean_mfma_kernel<KP, 8, 1>;
   }
 }
-mm_fn mm_pick_bf16(int P) {
+typedef void (*mb_fn)(const u32x4*, const float*, int, int, F16, F16, const float*, long long, int, float*);
+typedef void (*mprep_fn)(const float*, const float*, long long, int, F16, F16, u32x4*, float*, long long);
+mb_fn mm_pick_bf16(int P) {
   switch (P) {
     case 1: return mean_bf16_kernel<1, 2>;
     case 2: return mean_bf16_kernel<2, 2>;
@@ -443,6 +460,18 @@ mm_fn mm_pick_bf16(int P) {
     case 6: return mean_bf16_kernel<6, 1>;
     case 7: return mean_bf16_kernel<7, 1>;
     default: return mean_bf16_kernel<8, 1>;
+  }
+}
+mprep_fn mm_pick_prep(int P) {
+  switch (P) {
+    case 1: return mean_prep_kernel<1>;
+    case 2: return mean_prep_kernel<2>;
+    case 3: return mean_prep_kernel<3>;
+    case 4: return mean_prep_kernel<4>;
+    case 5: return mean_prep_kernel<5>;
+    case 6: return mean_prep_kernel<6>;
+    case 7: return mean_prep_kernel<7>;
+    default: return mean_prep_kernel<8>;
   }
 }
 }  // namespace
@@ -480,12 +509,27 @@ extern "C" int gpk_predict_mean_mfma(gpk_handle h, const float* X, const float* 
   int64_t chunk = (N + S - 1) / S;
   chunk = (chunk + MM_TJ - 1) / MM_TJ * MM_TJ;
   S = (N + chunk - 1) / chunk;
+  const size_t partial_bytes = ((size_t)S * M * P * sizeof(float) + 255) & ~(size_t)255;
   void* partial = nullptr;
-  GPK_TRY(gpk_scratch(h, (size_t)S * M * P * sizeof(float), &partial));
-  // D <= 14: distances on the bf16 matrix cores (exact three-way operand split, depth D + 2 <= 16);
-  // D = 15, 16: depth up to 17, nine fp32 MFMAs
-  hipLaunchKernelGGL(D > 14 ? mm_pick_p<9>(P) : mm_pick_bf16(P), dim3((unsigned)nqb, (unsigned)S), dim3(256), 0, h->stream, X, alpha,
-                     (long long)N, D, sc, ctr, Xq, (long long)M, (long long)chunk, (float*)partial);
+  if (D > 14) {
+    // D = 15, 16: depth up to 17, nine fp32 MFMAs per block, points staged through LDS
+    GPK_TRY(gpk_scratch(h, partial_bytes, &partial));
+    hipLaunchKernelGGL(mm_pick_p<9>(P), dim3((unsigned)nqb, (unsigned)S), dim3(256), 0, h->stream, X, alpha, (long long)N, D, sc,
+                       ctr, Xq, (long long)M, (long long)chunk, (float*)partial);
+  } else {
+    // D <= 14: distances on the bf16 matrix cores (exact three-way operand split, depth D + 2 <= 16); the training operand
+    // is prepared once per call (N x 96 bytes + alpha, behind the partial sums in the scratch block)
+    const int64_t nblk = (N + 31) / 32, npad = nblk * 32;
+    const size_t xb_bytes = (size_t)nblk * 192 * 16;
+    GPK_TRY(gpk_scratch(h, partial_bytes + xb_bytes + (size_t)npad * P * sizeof(float), &partial));
+    u32x4* xb = reinterpret_cast<u32x4*>((char*)partial + partial_bytes);
+    float* al = reinterpret_cast<float*>((char*)partial + partial_bytes + xb_bytes);
+    hipLaunchKernelGGL(mm_pick_prep(P), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, X, alpha, (long long)N, D,
+                       sc, ctr, xb, al, (long long)npad);
+    GPK_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(mm_pick_bf16(P), dim3((unsigned)nqb, (unsigned)S), dim3(256), 0, h->stream, (const u32x4*)xb,
+                       (const float*)al, (int)nblk, D, sc, ctr, Xq, (long long)M, (int)(chunk / 32), (float*)partial);
+  }
   GPK_LAUNCH_CHECK(h);
   const int64_t tot = M * P;
   hipLaunchKernelGGL(mean_mfma_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
