@@ -311,6 +311,21 @@ __global__ __launch_bounds__(256) void mean_prep_kernel(const float* __restrict_
   for (int p = 0; p < PP; ++p) al[(jb * PP + p) * 32 + t] = in ? alpha[j * PP + p] : 0.f;
 }
 
+// one halving step per lane-mask bit, MASK, MASK / 2, ...: v[0 .. CNT) -> v[0 .. CNT / 2)
+template <int CNT, int MASK, int STEPS>
+__device__ __forceinline__ void static_for_halving(float* v, int ln) {
+  if constexpr (STEPS > 0) {
+    const bool bit = (ln & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < CNT / 2; ++i) {
+      const float send = bit ? v[i] : v[i + CNT / 2];
+      const float keep = bit ? v[i + CNT / 2] : v[i];
+      v[i] = keep + __shfl_xor(send, MASK, 64);
+    }
+    static_for_halving<CNT / 2, MASK / 2, STEPS - 1>(v, ln);
+  }
+}
+
 template <int PP> struct MeanOperand { u32x4 bf[3]; float av[PP]; };
 
 template <int PP, int QB>
@@ -400,27 +415,35 @@ __global__ __launch_bounds__(256, 2) void mean_bf16_kernel(const u32x4* __restri
   }
   if (jj < nb) step(jj, R[0], R[1]);
 
+  // ---- sum over the 32 points a half-wave holds (lane & 31), by a halving butterfly: at the step with lane mask m a
+  // lane keeps one half of its values (by its bit m) and hands the other half to its partner, so the five steps move
+  // 48 + 24 + 12 + 6 + 3 values per lane pair instead of 5 x 96.  With the values flattened as k = (b 16 + r) PP + p a lane
+  // ends with k = PP (lane & 31) + p: the complete sums of query row r = lane & 15 of block b = (lane & 31) >> 4.
+  // (QB = 1: four halving steps and a plain exchange for mask 1; lanes 2 i and 2 i + 1 then both hold row i.)
+  constexpr int NV = QB * 16 * PP;
+  float v[NV];
 #pragma unroll
   for (int b = 0; b < QB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v[PP];
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int p = 0; p < PP; ++p) {
-        float t = (r & 1) ? acc[b][r >> 1][p].y : acc[b][r >> 1][p].x;
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
-        t += __shfl_xor(t, 16, 64);
-        v[p] = t;
+        v[(b * 16 + 2 * i) * PP + p] = acc[b][i][p].x;
+        v[(b * 16 + 2 * i + 1) * PP + p] = acc[b][i][p].y;
       }
-      const long long q = q0 + (wave * QB + b) * 32 + acc_row(r, lane);
-      if (ln == 0 && q < M) {
+  static_for_halving<NV, 16, (QB == 2 ? 5 : 4)>(v, ln);
+  if constexpr (QB == 1) {
 #pragma unroll
-        for (int p = 0; p < PP; ++p) partial[((long long)blockIdx.y * M + q) * PP + p] = v[p];
-      }
+    for (int p = 0; p < PP; ++p) v[p] += __shfl_xor(v[p], 1, 64);
+  }
+  {
+    const int row = QB == 2 ? (ln & 15) : (ln >> 1), b = QB == 2 ? (ln >> 4) : 0;
+    const long long q = q0 + (wave * QB + b) * 32 + acc_row(row, lane);
+    if ((QB == 2 || (ln & 1) == 0) && q < M) {
+#pragma unroll
+      for (int p = 0; p < PP; ++p) partial[((long long)blockIdx.y * M + q) * PP + p] = v[p];
     }
+  }
 }
 
 __global__ void mean_mfma_reduce_kernel(const float* __restrict__ partial, int S, long long M, int P, float sf2,
