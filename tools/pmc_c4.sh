@@ -1,4 +1,5 @@
 #!/bin/bash
+# Counter passes over the matrix-pipe mean kernel at C4 (one rocprofv3 --pmc run per counter set); summary in gpurun_out/pmc_c4/pmc_c4.txt
 out=gpurun_out/pmc_c4; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0

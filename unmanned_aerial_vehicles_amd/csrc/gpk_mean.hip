@@ -26,7 +26,7 @@
 // (query row (r & 3) + 8 (r >> 2) + 4 (l >> 5), training point l & 31): a lane keeps ONE training point per
 // block, so alpha_j are per-lane values and its 16 x P running sums belong to 16 queries; the 32 lanes of a
 // half-wave are combined once, after the loop over the training chunk.  Measured on MI355X (N = 65536,
-// D = 9, P = 3, 2^20 queries): 15.4 ms against 46.6 ms for the VALU kernel; vector-ALU bound.
+// D = 9, P = 3, 2^20 queries): 14.1 ms against 43.6 ms for the VALU kernel; vector-ALU bound.
 //
 // Reference: the mean of sklearn _gpr.py:443-447 / RBF.__call__ kernels.py:1564-1565 and
 // quadrotor_gp_mpc/gaussian_process.py:223-226 (same value; fp32 arithmetic).
