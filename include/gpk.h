@@ -199,9 +199,13 @@ GPK_API int gpk_predict_host_multi(gpk_handle h, int B, const double* const* X, 
                            const double* Xq_host, int64_t M, double* mean_host, double* var_host);
 
 /* K4 on the matrix cores, fp32 only: the same posterior mean as gpk_predict_mean(GPK_F32, ...), with the
- * pairwise squared distances of 32 x 32 (query, training point) blocks formed by v_mfma_f32_32x32x2_f32
- * from centred, scaled coordinates (|a|^2 + |b|^2 - 2 a.b: one augmented dot product of length D + 1) and
- * only exp2 + P FMAs per pair left on the vector ALU.  center: host double[D], a point near the data (the
+ * pairwise squared distances of 32 x 32 (query, training point) blocks formed by MFMAs from centred, scaled
+ * coordinates (|a|^2 + |b|^2 - 2 a.b as ONE augmented dot product of depth D + 2) and only exp2 + P FMAs per
+ * pair left on the vector ALU.  D <= 14: six v_mfma_f32_32x32x16_bf16 per block on an exact three-way bf16
+ * split of every fp32 operand (fp32-accurate distances); the training side is centred, scaled and split once
+ * per call into MFMA-fragment order (N x 96 bytes of the handle's scratch) and loaded from L2 straight into
+ * registers.  D = 15, 16: nine v_mfma_f32_32x32x2_f32.  The training set is cut into chunks of <= 2048
+ * points whose partial sums are added in fp64.  center: host double[D], a point near the data (the
  * training mean); the expansion is accurate to ~|u|^2 * 2^-23 in the exponent, u = (x - center) / ls, so
  * callers use it while max |u|^2 is modest (device.py: <= 64) and the exact-difference kernel otherwise.
  * D <= 16, P <= 8.  Replaces the same reference lines as gpk_predict_mean.                              */
