@@ -255,8 +255,9 @@ GPK_API int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, 
  * [mean[m][0..P) | var[m] y_std[p]^2, p = 0..P) - K4 (gpk_predict_mean_mfma when `center` is given, else
  * gpk_predict_mean(GPK_F32)) into mean_tmp (dev float[M * P]), then gpk_predict_var_inv_split2's launch with the variance's
  * un-normalisation (sklearn/gaussian_process/_gpr.py:487-489) and the packing folded into its finalising kernel; that
- * kernel also adds to *low_count (dev, nullable; the caller zeroes it) the number of rows whose normalised variance is
- * below `recheck_below` - the rows the fp32 serving gate recomputes in fp64.
+ * kernel also adds to *low_count (dev, nullable; a running counter: the caller reads it before and after, or zeroes
+ * it) the number of rows whose normalised variance is below `recheck_below` - the rows the fp32 serving gate
+ * recomputes in fp64.
  * gpk_pack_mean_var: the same rows from a separate mean (dev M x P of `dtype`) and normalised variance (dev double[M]) -
  * for the serving paths whose variance comes from another launch.  P <= 16.                                          */
 GPK_API int gpk_predict_mean_var_split2(gpk_handle h, const float* X, const float* alpha, int64_t N, int D, int P,

@@ -48,6 +48,10 @@ class Backend:
         self.h = h
         self.lock = threading.RLock()
         self.bind_stream()
+        # running count of the rows the fp32 variance gate sent back (the packed finalise kernel adds to it and nobody
+        # resets it: a serving call reads it before and after under the lock, so no fill kernel runs per call)
+        self.low_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self.low_seen = 0
 
     def bind_stream(self):
         torch = _torch()
@@ -658,8 +662,8 @@ class DeviceGP:
         panel = min(panel, padded(M))
         work2 = be.empty((self.Np * panel * 4,), torch.uint8)
         mean_tmp = be.empty((panel * self.P,), torch.float32)
-        count = torch.zeros((1,), dtype=torch.int32, device=be.device) if gated else None
         thr = self.FP32_VAR_RECHECK_FRACTION * kss if gated else 0.0
+        nlow = 0
         with be.lock:
             be.bind_stream()
             for m0 in range(0, M, panel):
@@ -668,8 +672,12 @@ class DeviceGP:
                     be.h, _p(c["X"]), _p(c["alpha"]), self.N, self.D, self.P, self.ls.ctypes.data_as(_lib._dp), self.sf2,
                     center, ym.ctypes.data_as(_lib._dp), ys.ctypes.data_as(_lib._dp), _p(W2), _p(w_scales), self.Np,
                     _p(q[m0:m1]), m1 - m0, float(kss), float(floor), _p(work2), _p(mean_tmp), float(thr),
-                    _p(count) if gated else None, _p(out[m0:m1])))
-        if gated and int(count.item()):          # (a 4-byte read-back; rows to recompute are rare: near training points only)
+                    _p(be.low_count) if gated else None, _p(out[m0:m1])))
+            if gated:                            # (a 4-byte read-back; rows to recompute are rare: near training points only)
+                seen = int(be.low_count.item()) & 0xFFFFFFFF
+                nlow = (seen - be.low_seen) & 0xFFFFFFFF
+                be.low_seen = seen
+        if nlow:
             ys2 = torch.as_tensor(ys ** 2, device=be.device)
             low = torch.nonzero(out[:, self.P] < thr * float(ys[0] ** 2)).ravel()
             v64 = self.predict_var_dev(q[low].double().contiguous(), kss, floor, "float64", self._fp64_var_method())
