@@ -318,7 +318,8 @@ def test_predict_mean_fp64_fp32(be, csv_data, ka):
 @pytest.mark.parametrize("N,D,P,M,ls", [(1000, 9, 3, 257, 2.0), (5000, 9, 3, 10000, 2.0), (777, 10, 6, 25, 1.5),
                                          (300, 16, 8, 7, 3.0), (129, 1, 1, 1, 0.7), (2048, 4, 4, 600, 1.0),
                                          (640, 15, 5, 130, 2.5), (500, 14, 2, 100, 2.0), (400, 7, 5, 90, 2.0),
-                                         (350, 3, 7, 45, 1.2), (260, 12, 8, 33, 2.5), (2100, 9, 3, 300, 2.0)])
+                                         (350, 3, 7, 45, 1.2), (260, 12, 8, 33, 2.5), (2100, 9, 3, 300, 2.0),
+                                         (20, 3, 2, 40, 1.0), (33, 5, 3, 70, 1.5)])
 def test_predict_mean_mfma(be, N, D, P, M, ls):
     """K4 on the matrix cores (fp32, centred expansion of the squared distance) against the fp64 oracle
     and the exact-difference fp32 kernel: same posterior mean within the fp32 tolerance (1e-4 of the
