@@ -10,8 +10,8 @@
 //
 //  * D <= 14 (mean_bf16_kernel; |u_q|^2 rides along as one more component, depth D + 2): the dot product runs on the
 //    bf16 matrix pipe at fp32 accuracy.  Every fp32
-//    operand is split EXACTLY into three bf16 parts (x = x0 + x1 + x2, 8 significant bits each, by
-//    truncation; the remainders are exact in fp32) and the product becomes six v_mfma_f32_32x32x16_bf16
+//    operand is split EXACTLY into three bf16 parts (x = x0 + x1 + x2, 8 significant bits each, rounded to
+//    nearest; the remainders are exact in fp32) and the product becomes six v_mfma_f32_32x32x16_bf16
 //    (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0; the dropped terms are below 2^-24 of |a||b|; bf16 x bf16
 //    products are exact and accumulate in fp32): 192 matrix-pipe cycles per block.
 //  * D = 15, 16 (mean_mfma_kernel, depth up to 17): nine v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  That
