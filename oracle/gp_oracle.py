@@ -300,3 +300,21 @@ def synthetic_problem(N, M, D=9, P=3):
     Y = np.sin(X @ W) + 0.1 * rng.standard_normal((N, P))
     Xq = np.random.default_rng(1).standard_normal((M, D))
     return X, Y, Xq
+
+
+def synthetic_flight_problem(N, D=10, P=6, seed=7):
+    """Flight-like training rows for the reference's offline-training workload (src/px4/train_gp_offline.py:124-140 ->
+    src/px4/simple_gp.py:156-185: N <= 10 000 rows of [x, y, z, vx, vy, vz, ax, ay, az, yaw_rate] -> 6 residuals).
+    Deterministic: positions / velocities / accelerations of unit-ish scale, a numerically silent yaw-rate column (as in
+    the flight CSVs), residuals = a smooth drag-like function of velocity and acceleration + sensor noise, of the
+    magnitude the CSVs hold (1e-2).  `bench.py --workload train` carries the same generator."""
+    rng = np.random.default_rng(seed)
+    X = 0.6 * rng.standard_normal((N, D))
+    X[:, 2] -= 3.0                              # altitude around -3 m (NED)
+    if D >= 10:
+        X[:, 9] *= 1e-3                         # yaw rate: almost constant
+    W = rng.standard_normal((6, P))
+    va = X[:, 3:9]
+    Y = 0.03 * np.sin(va @ W) - 0.01 * np.pad(va[:, :3] * np.abs(va[:, :3]), ((0, 0), (0, max(P - 3, 0))))[:, :P]
+    Y = Y + 0.005 * rng.standard_normal((N, P))
+    return X, Y

@@ -10,7 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libgpk.so")
-SOURCES = ["gpk_api.hip", "gpk_gram.hip", "gpk_gemm.hip", "gpk_chol.hip", "gpk_grad.hip", "gpk_mean.hip", "gpk_k5split.hip", "gpk_small.hip",
+SOURCES = ["gpk_api.hip", "gpk_gram.hip", "gpk_gemm.hip", "gpk_chol.hip", "gpk_ptile.hip", "gpk_grad.hip", "gpk_mean.hip", "gpk_k5split.hip", "gpk_small.hip",
            "gpk_model.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

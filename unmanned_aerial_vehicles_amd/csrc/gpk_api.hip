@@ -34,6 +34,8 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_TRSM256")) h->trsm256 = atoi(e);
   if (const char* e = getenv("GPK_TRTRI_LEVELS")) h->trtri_levels = atoi(e);
   if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
+  if (const char* e = getenv("GPK_PTILE")) h->ptile = atoi(e);
+  if (const char* e = getenv("GPK_PTILE_MAX_NP")) h->ptile_max_np = atoi(e);
   if (getenv("GPK_DEBUG_FILL")) h->debug_fill = 1;
   *out = h;
   return GPK_OK;
@@ -48,6 +50,7 @@ extern "C" void gpk_destroy(gpk_handle h) {
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->d_small) (void)hipFree(h->d_small);
   if (h->d_count) (void)hipFree(h->d_count);
+  if (h->d_ptile) (void)hipFree(h->d_ptile);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->serve_dev) (void)hipFree(h->serve_dev);
   if (h->serve_host) (void)hipHostFree(h->serve_host);
@@ -86,6 +89,8 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "trtri_levels") h->trtri_levels = value;
   else if (n == "gemm_small_tiles") h->gemm_small_tiles = value;
   else if (n == "k3_stream_min_np") h->k3_stream_min_np = value;
+  else if (n == "ptile") h->ptile = value;
+  else if (n == "ptile_max_np") h->ptile_max_np = value;
   else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
   return GPK_OK;
 }

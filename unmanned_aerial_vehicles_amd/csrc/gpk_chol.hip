@@ -706,10 +706,13 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, doubl
   GPK_REQUIRE(h, ((uintptr_t)A % 16) == 0 && ((uintptr_t)winv % 16) == 0, "potrf: A, winv must be 16-byte aligned");
   const int nb = h->batch;                         // batched mode: info receives one entry per problem
   GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, nb * sizeof(int), h->stream));
-  GPK_TRY(potrf_rec(h, A, lda, Np, winv, 0));
+  int one_launch = 0;
+  GPK_TRY(gpk_potrf_ptile(h, A, Np, lda, winv, 0, &one_launch));
+  if (!one_launch) GPK_TRY(potrf_rec(h, A, lda, Np, winv, 0));
   int hinfo_all[GPK_MAX_BATCH] = {0};
   GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo_all, h->d_info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  if (one_launch) GPK_TRY(gpk_potrf_ptile_check(h));
   int hinfo = 0;
   for (int b = 0; b < nb; ++b) {
     info[b] = hinfo_all[b];

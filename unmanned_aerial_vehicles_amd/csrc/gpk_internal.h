@@ -43,6 +43,12 @@ struct gpk_context {
   int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
   int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
                              // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
+  int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 256 <= Np <= ptile_max_np (GPK_PTILE=0: recursion)
+  int ptile_max_np = 16384;
+  int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
+  int ptile_slots = 512;     // workgroups that fit the device at two per CU
+  std::string ptile_trace_path;   // GPK_PTILE_TRACE (debugging aid): where the next launch's time stamps go
+  long long ptile_trace_n = 0;
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
   int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
   // gpk_timing: HIP-event brackets around the dominant launches (K5 variance GEMM, K1 Gram kernel), a ring of pairs
@@ -91,6 +97,12 @@ struct gpk_context {
   } while (0)
 
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
+
+// ---- one-launch tile Cholesky (gpk_ptile.hip) -----------------------------------------
+constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row counters
+// *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
+int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used);
+int gpk_potrf_ptile_check(gpk_handle h);
 void gpk_model_free(gpk_handle h);   // gpk_model.hip
 
 // Event brackets of gpk_timing (no-ops unless enabled): record the first event, launch, record the second.

@@ -1,0 +1,499 @@
+// One-launch tile Cholesky: the whole factorisation of an Np x Np matrix (Np <= 16 384 by default), and with it the
+// inverses of its 128 x 128 diagonal tiles, as ONE persistent kernel.  Replaces scipy.linalg.cholesky at
+// sklearn/gaussian_process/_gpr.py:349,587 for the sizes the reference trains at (src/px4/simple_gp.py:170-177: N <= 10 000;
+// src/px4/gp_trainer.py:169-179).
+//
+// The recursive gpk_potrf (gpk_chol.hip) is a chain of ~3 N / 128 dependent launches; at N = 4096 those launches are
+// small and latency-bound and the factorisation runs at 8 % of the fp64 matrix pipe.  Here the matrix is a grid of
+// 128 x 128 tiles and every tile is one TASK, handed out in column-major order by a device-side ticket counter:
+//
+//   T(i, j), i > j :  X = (A_ij - sum_{k<j} L_ik L_jk^T) W_jj^T        (W_jj = L_jj^-1, from T(j, j))
+//   T(j, j)        :  A_jj - sum_{k<j} L_jk L_jk^T  ->  L_jj, W_jj      (the leaf, in registers)
+//
+// A task accumulates its k-sum in registers (left-looking: the tile is read once and written once), waits on a monotone
+// per-tile-row counter ready[i] = "tiles (i, 0 .. ready[i] - 1) are final" before each 128-wide k-step and publishes its
+// tile by raising ready[i].  Tasks are taken in list order by workgroups that are RUNNING, and a task waits only for
+// tasks earlier in the list, so the earliest unfinished task can always proceed: no deadlock whatever the residency.
+//
+// Register layouts are chosen so that the two dependent steps of the critical path need no data movement:
+//   * an off-diagonal task keeps its tile TRANSPOSED, wave w = rows 16 w .. 16 w + 15 of the tile as eight 16 x 16
+//     accumulator blocks XT[kb] (element [m][n] = tile[16 w + n][16 kb + m]).  An accumulator block in the f64 C/D map
+//     (row = (lane >> 4) + 4 reg, column = lane & 15) IS the B operand of v_mfma_f64_16x16x4_f64 for k-step `reg`,
+//     so X^T = W_jj X^^T runs straight from the accumulators (A = blocks of W_jj from LDS), in place.
+//   * the diagonal task keeps the lower triangle the same way (wave = one block row r: blocks (r, 0 .. r) transposed,
+//     later the blocks of column r of the inverse) and factors it right-looking: the 16 x 16 diagonal block and its
+//     inverse by ONE wave in registers (gpk_p2.h), the blocks below it by W_bb * (accumulator), the trailing update and
+//     the forward substitution for the inverse by L_(i, b) (one block column of L in LDS) * (accumulator).  While one
+//     wave works on a diagonal block the other seven apply the previous block column.
+//
+// Visibility (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the XCDs' L2s are
+// not coherent with each other, so every byte that is handed from one workgroup to another inside the launch (final
+// off-diagonal tiles, W_jj) is written with sc1 (write-through) stores and read with sc1 loads; each storing wave waits
+// for its stores (s_waitcnt vmcnt(0)), a workgroup barrier follows, and ONE lane raises the counter with an sc1 store;
+// consumers poll it with sc1 loads.  A tile is written exactly once and never read before it is final, so no XCD can
+// hold a stale copy.  L_jj (nobody reads it inside the launch) uses plain stores.
+// Every spin loop gives up after GPK_PTILE_TIMEOUT_TICKS of the 100 MHz real-time counter and raises an abort word that
+// every other loop polls: the grid always drains.
+#include <cstdlib>
+
+#include "gpk_internal.h"
+#include "gpk_p2.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double dv2 __attribute__((ext_vector_type(2)));
+typedef unsigned int V16 __attribute__((ext_vector_type(4)));
+
+constexpr int TS = 128;                       // tile edge
+constexpr int BK = 16;                        // doubles per k-tile (128 bytes)
+constexpr int NT = 512;                       // threads per workgroup (8 waves)
+constexpr int ROWB = 144;                     // bytes per staged row (128 + 16 pad: conflict-free 16-byte fragment reads)
+constexpr int OPB = TS * ROWB;                // one operand k-tile in LDS
+constexpr int BS = 17;                        // row stride (doubles) of a 16 x 16 block in LDS (conflict-free 8-byte reads)
+constexpr int BLK = 16 * BS;                  // doubles per block
+constexpr int OS = 66;                        // row stride (doubles) of the 128 x 64 output staging image
+constexpr int LDS_BYTES = 80 * 1024;          // two workgroups per CU
+constexpr int CTL_OFF = LDS_BYTES - 64;       // a few control words at the end
+constexpr long long GPK_PTILE_TIMEOUT_TICKS = 400000000ll;   // 4 s of s_memrealtime
+
+static_assert(4 * OPB <= CTL_OFF, "staging buffers");
+static_assert(36 * BLK * 8 <= CTL_OFF, "W_jj image");
+static_assert(TS * OS * 8 <= CTL_OFF, "output staging image");
+static_assert((1 + 8 + 16) * BLK * 8 <= CTL_OFF, "leaf work area");
+
+struct PTParams {
+  double* A; long long lda; long long strideA;     // strides between the problems of a batch, in bytes
+  double* winv; long long strideW;
+  int* info; int row0;
+  int nt, batch, ntasks;
+  int* ctrl;                                       // [0] ticket counter, [1] abort; ready counters from ctrl + 16
+  long long* trace;                                // GPK_PTILE_TRACE: 16 time stamps per task (100 MHz), or null
+};
+
+template <int V> struct IC { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) { f(IC<I>{}); sfor<I + 1, N>(f); }
+}
+
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The thread index again, opaque to the optimiser: every section of the kernel derives its per-lane offsets from a
+// fresh copy, so that they live for that section only.  (Derived from ONE tid they are loop invariants of the task
+// loop; the register allocator then spills them around the register-hungry sections and reloads them inside the
+// k-loop, where every reload's s_waitcnt also waits for the operand prefetch just issued.)
+__device__ __forceinline__ int fresh_tid() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+// one lane: spin until min(*ra, *rb) >= need (rb may be null); -1 when the launch is aborted
+__device__ int poll_ready(const int* ra, const int* rb, int need, int* abortp) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0;; ++it) {
+    int v = ld_agent(ra);
+    if (rb) v = min(v, ld_agent(rb));
+    if (v >= need) return v;
+    if ((it & 31) == 31) {
+      if (ld_agent(abortp) != 0) return -1;
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GPK_PTILE_TIMEOUT_TICKS) { st_agent(abortp, 1); return -1; }
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// global -> registers: k-tile of one operand panel (128 rows x 16 doubles), two 16-byte chunks per thread, sc1
+__device__ __forceinline__ void load_ktile(const char* base, const unsigned (&voff)[2], V16 (&r)[2]) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+  r[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[0], 0, 16);
+  r[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[1], 0, 16);
+}
+__device__ __forceinline__ void store_ktile(char* lds, int tid, const V16 (&r)[2]) {
+  const int c = tid & 7, rr = tid >> 3;
+  *reinterpret_cast<V16*>(lds + rr * ROWB + c * 16) = r[0];
+  *reinterpret_cast<V16*>(lds + (rr + 64) * ROWB + c * 16) = r[1];
+}
+
+// 4 MFMAs: acc += A(16 x 16 block in LDS, row-major, stride BS) * B(accumulator block `b` in the C/D map)
+// A element [m][kk] is read at ablk[m * BS + kk] (TRANS == false) or ablk[kk * BS + m] (TRANS == true)
+template <bool TRANS>
+__device__ __forceinline__ d4 blk_mfma(const double* ablk, const d4& b, d4 acc, int lr, int lq) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int kk = lq + 4 * t;
+    const double a = TRANS ? ablk[kk * BS + lr] : ablk[lr * BS + kk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+#define PT_STAMP(k) do { if (p.trace && tid == 0) p.trace[(long long)task * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+
+__global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  int* ctl = reinterpret_cast<int*>(lds + CTL_OFF);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int* abortp = p.ctrl + 1;
+  const int nt = p.nt;
+  const long long ntp = (long long)nt * (nt + 1) / 2;
+
+  for (;;) {
+    __syncthreads();                                  // the previous task is done with LDS and with ctl
+    if (tid == 0) {
+      int t = __hip_atomic_fetch_add(p.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t < p.ntasks && ld_agent(abortp) != 0) t = p.ntasks;
+      ctl[0] = t;
+    }
+    __syncthreads();
+    const int task = ctl[0];
+    if (task >= p.ntasks) return;
+    PT_STAMP(0);
+    // task -> (problem b, tile row i, tile column j); column-major list: column j starts at j nt - j (j - 1) / 2
+    const int b = task % p.batch;
+    const long long tt = task / p.batch;
+    int j = (int)(((double)(2 * nt + 1) - __builtin_sqrt((double)(2 * nt + 1) * (2 * nt + 1) - 8.0 * (double)tt)) * 0.5);
+    j = max(0, min(j, nt - 1));
+    while (j > 0 && (long long)j * nt - (long long)j * (j - 1) / 2 > tt) --j;
+    while ((long long)(j + 1) * nt - (long long)(j + 1) * j / 2 <= tt) ++j;
+    const int i = j + (int)(tt - ((long long)j * nt - (long long)j * (j - 1) / 2));
+    (void)ntp;
+    double* A = reinterpret_cast<double*>(reinterpret_cast<char*>(p.A) + (long long)b * p.strideA);
+    double* Wv = reinterpret_cast<double*>(reinterpret_cast<char*>(p.winv) + (long long)b * p.strideW);
+    int* ready = p.ctrl + 16 + b * nt;
+    const long long lda = p.lda;
+    double* Atile = A + (long long)i * TS * lda + (long long)j * TS;
+    const bool diag = (i == j);
+    // block row owned by this wave: the diagonal task pairs a long and a short row on every SIMD (waves w, w + 4)
+    const int rw = diag ? (wave < 4 ? wave : 11 - wave) : wave;
+
+    // ---- accumulators start from the tile itself (transposed blocks)
+    d4 S[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};
+    {
+      const int t0 = fresh_tid(), lr = t0 & 15, lq = (t0 >> 4) & 3;
+      const double* src = Atile + (long long)(16 * rw + lr) * lda + lq;
+      sfor<0, 8>([&](auto kc) {          // (a diagonal task reads its blocks right of the diagonal too: valid memory,
+        constexpr int KB = decltype(kc)::value;   //  they ride along through the k-loop and are dropped after it)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S[KB][t] = src[16 * KB + 4 * t];
+      });
+    }
+
+    // ---- k-loop over the finished tile columns 0 .. j - 1 (8 k-tiles each), register-staged pipeline as in gpk_gemm.hip
+    const int nkt = 8 * j;
+    if (nkt > 0) {
+      const char* pj = reinterpret_cast<const char*>(A + (long long)j * TS * lda);     // row panel j: A operand
+      const char* pi = reinterpret_cast<const char*>(A + (long long)i * TS * lda);     // row panel i: B operand
+      const int tk = fresh_tid(), lr = tk & 15, lq = (tk >> 4) & 3;
+      unsigned voff[2];
+      {
+        const int c = tk & 7, rr = tk >> 3;
+        voff[0] = (unsigned)(((long long)rr * lda + c * 2) * 8);
+        voff[1] = (unsigned)(((long long)(rr + 64) * lda + c * 2) * 8);
+      }
+      int avail = 0;                                   // tile columns known to be final in rows i and j
+      auto need_cols = [&](int need) -> bool {        // uniform; false = aborted
+        if (avail >= need) return true;
+        if (tid == 0) ctl[1] = poll_ready(ready + i, diag ? nullptr : ready + j, need, abortp);
+        __syncthreads();
+        const int v = ctl[1];
+        __syncthreads();
+        if (v < 0) return false;
+        avail = min(v, j);
+        return true;
+      };
+      if (!need_cols(1)) return;
+      V16 ra[2], rb[2];
+      load_ktile(pj, voff, ra);
+      load_ktile(pi, voff, rb);
+      store_ktile(lds, tk, ra);
+      store_ktile(lds + OPB, tk, rb);
+      {
+        const int k1 = min(1, nkt - 1);
+        load_ktile(pj + k1 * (BK * 8), voff, ra);
+        load_ktile(pi + k1 * (BK * 8), voff, rb);
+      }
+      __syncthreads();
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        store_ktile(lds + (cur ^ 1) * 2 * OPB, tk, ra);
+        store_ktile(lds + (cur ^ 1) * 2 * OPB + OPB, tk, rb);
+        const int kn = min(kt + 2, nkt - 1);
+        if (!need_cols((kn >> 3) + 1)) return;
+        load_ktile(pj + (long long)kn * (BK * 8), voff, ra);
+        load_ktile(pi + (long long)kn * (BK * 8), voff, rb);
+        const char* la = lds + cur * 2 * OPB;                     // rows of panel j
+        const char* lb = la + OPB;                                // rows of panel i (the same rows in a diagonal task)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          dv2 bf = *reinterpret_cast<const dv2*>(lb + (16 * rw + lr) * ROWB + (4 * lq + 2 * hh) * 8);
+          bf.x = -bf.x; bf.y = -bf.y;
+          sfor<0, 2>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            dv2 af[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+              af[x] = *reinterpret_cast<const dv2*>(la + (16 * (4 * G + x) + lr) * ROWB + (4 * lq + 2 * hh) * 8);
+            sfor<0, 4>([&](auto xc) {
+              constexpr int KB = 4 * G + decltype(xc)::value;
+              S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].x, bf.x, S[KB], 0, 0, 0);
+              S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].y, bf.y, S[KB], 0, 0, 0);
+            });
+          });
+        }
+        __syncthreads();
+      }
+    }
+
+    PT_STAMP(1);
+    if (!diag) {
+      // =================================================== off-diagonal task: X^T = W_jj X^^T, in place, then publish
+      if (tid == 0) ctl[1] = poll_ready(ready + j, nullptr, j + 1, abortp);
+      __syncthreads();
+      if (ctl[1] < 0) return;
+      PT_STAMP(2);
+      const int ta = fresh_tid(), lr = ta & 15, lq = (ta >> 4) & 3;
+      double* wl = reinterpret_cast<double*>(lds);
+      {
+        // the 36 lower blocks of W_jj (128 x 128 row-major) -> block-major LDS image, block (mb, kb) at mb (mb + 1) / 2 + kb
+        const double* wj = Wv + (long long)j * TS * TS;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(wj), 0, 0x7fffffff, 0x00020000);
+#pragma unroll 1
+        for (int u0 = 0; u0 < 9; u0 += 3) {
+          V16 v[3];
+          int dst[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int e = ta + NT * (u0 + u), blk = e >> 7, rowb = (e & 127) >> 3, cp = e & 7;
+            int mb = 0;
+            while ((mb + 1) * (mb + 2) / 2 <= blk) ++mb;
+            const int kb = blk - mb * (mb + 1) / 2;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((16 * mb + rowb) * TS + 16 * kb + 2 * cp) * 8), 0, 16);
+            dst[u] = blk * BLK + rowb * BS + 2 * cp;
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const dv2 d = __builtin_bit_cast(dv2, v[u]);
+            wl[dst[u]] = d.x;
+            wl[dst[u] + 1] = d.y;
+          }
+        }
+      }
+      __syncthreads();
+      PT_STAMP(3);
+      sfor<0, 8>([&](auto mc) {
+        constexpr int MB = 7 - decltype(mc)::value;               // descending: block MB needs the OLD blocks 0 .. MB only
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        sfor<0, MB + 1>([&](auto kc) {
+          constexpr int KB = decltype(kc)::value;
+          acc = blk_mfma<false>(wl + (MB * (MB + 1) / 2 + KB) * BLK, S[KB], acc, lr, lq);
+        });
+        S[MB] = acc;
+      });
+      PT_STAMP(4);
+      __syncthreads();                                            // every wave is done with the W image
+      // S[mb][t] (lane n = lr, q = lq) = L_ij[16 w + n][16 mb + q + 4 t]: through LDS in two column halves, then
+      // whole 512-byte row pieces with 16-byte sc1 stores
+      double* ob = reinterpret_cast<double*>(lds);
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(Atile, 0, 0x7fffffff, 0x00020000);
+      sfor<0, 2>([&](auto hc) {
+        constexpr int hf = decltype(hc)::value;
+        sfor<0, 4>([&](auto mc) {
+          constexpr int ML = decltype(mc)::value;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ob[(16 * wave + lr) * OS + 16 * ML + lq + 4 * t] = S[ML + 4 * hf][t];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = ta + NT * u, row = e >> 5, c2 = e & 31;
+          const V16 v = *reinterpret_cast<const V16*>(ob + row * OS + 2 * c2);
+          __builtin_amdgcn_raw_buffer_store_b128(v, ro, (unsigned)(((long long)row * lda + 64 * hf + 2 * c2) * 8), 0, 16);
+        }
+        __syncthreads();
+      });
+      wait_vm0();
+      __syncthreads();
+      if (tid == 0) st_agent(ready + i, j + 1);
+      PT_STAMP(5);
+      continue;
+    }
+
+    // ======================================================= diagonal task: L_jj and W_jj = L_jj^-1 from the accumulators
+    // Slot S[k] of the wave that owns block row / column rw:  k <= rw: block (rw, k) of the updated tile, transposed,
+    // until block column k is final (then L(rw, k)^T, needed for one more step);  k >= rw: block (k, rw) of the forward
+    // substitution for the inverse (R = -sum L W, then W(k, rw)).  Slot rw changes hands when the wave's own diagonal
+    // block has gone to the factoring wave.
+    const int tl = fresh_tid(), lane = tl & 63, lr = tl & 15, lq = (tl >> 4) & 3;
+    double* dblk = reinterpret_cast<double*>(lds);                // the current diagonal block, row-major
+    double* wd = dblk + BLK;                                      // wd[b][r][c] = W_bb[c][r]
+    double* lcol = wd + 8 * BLK;                                  // two block columns of L: lcol[buf][block row]
+    double* Wj = Wv + (long long)j * TS * TS;
+    int* info = p.info + b;
+    __syncthreads();                                              // the k-loop's last reads of the staging buffers
+    sfor<1, 8>([&](auto kc) {                                     // the blocks right of the diagonal are not part of the task
+      constexpr int KB = decltype(kc)::value;
+      if (KB > rw) S[KB] = d4{0.0, 0.0, 0.0, 0.0};
+    });
+    if (rw == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[0][t];
+    }
+    __syncthreads();
+    sfor<0, 8>([&](auto jc) {
+      constexpr int JB = decltype(jc)::value;
+      double* lc = lcol + (JB & 1) * 8 * BLK;                     // block column JB of L
+      // ---- phase A: one wave factors the diagonal block; the others apply block column C = JB - 1:
+      //      S[X] -= L(X, C) * S[C] for X = C + 1 .. rw (factor rows) or C + 1 .. 7 (inverse columns, rw <= C)
+      if (rw == JB) {
+        const int bad = gpk_p2_factor(dblk, BS, lc + JB * BLK, BS, wd + JB * BLK, BS, lane, S);
+        if (bad != 0 && lane == 0) atomicCAS(info, 0, p.row0 + TS * j + 16 * JB + bad);
+        if (lane < 16) {                                          // L_bb: lower triangle only (the tile's upper part stays)
+          double* dst = Atile + (long long)(16 * JB + lane) * lda + 16 * JB;
+#pragma unroll
+          for (int c = 0; c < 16; ++c)
+            if (c <= lane) dst[c] = lc[JB * BLK + lane * BS + c];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
+      } else if constexpr (JB > 0) {
+        constexpr int C = JB - 1;
+        const double* pc = lcol + (C & 1) * 8 * BLK;
+        const int hi = rw > C ? rw : 7;
+        const d4 nb = -S[C];
+        double an[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) an[t] = pc[(C + 1) * BLK + lr * BS + lq + 4 * t];
+        sfor<C + 1, 8>([&](auto xc) {
+          constexpr int X = decltype(xc)::value;
+          double ac[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ac[t] = an[t];
+          if constexpr (X < 7) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) an[t] = pc[(X + 1) * BLK + lr * BS + lq + 4 * t];
+          }
+          if (X <= hi && !(X == C + 1 && rw == C + 1)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) S[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], nb[t], S[X], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      __syncthreads();
+      PT_STAMP(2 + JB);
+      // ---- phase B: S[JB] <- W_bb * S[JB]: below the diagonal block that is L(rw, JB)^T, in the columns of the inverse
+      //      W(JB, rw); the wave of the diagonal block itself takes W_bb as it stands
+      if (rw == JB) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S[JB][t] = wd[JB * BLK + lr * BS + lq + 4 * t];
+      } else {
+        S[JB] = blk_mfma<true>(wd + JB * BLK, S[JB], d4{0.0, 0.0, 0.0, 0.0}, lr, lq);
+      }
+      if (rw > JB) {
+        double* dst = Atile + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          lc[rw * BLK + lr * BS + lq + 4 * t] = S[JB][t];
+          dst[4 * t] = S[JB][t];
+        }
+      } else {
+        double* dst = Wj + (long long)(16 * JB + lq) * TS + 16 * rw + lr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      // ---- phase C: the next diagonal block gets its last update and goes to LDS
+      if constexpr (JB < 7) {
+        if (rw == JB + 1) {
+          const d4 nb = -S[JB];
+          S[JB + 1] = blk_mfma<false>(lc + (JB + 1) * BLK, nb, S[JB + 1], lr, lq);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[JB + 1][t];
+        }
+        __syncthreads();
+      }
+    });
+    wait_vm0();
+    __syncthreads();
+    if (tid == 0) st_agent(ready + j, j + 1);
+    PT_STAMP(10);
+  }
+}
+
+}  // namespace
+
+// Factor the Np x Np matrix A (lower triangle, in place) and write the inverses of its diagonal tiles to winv, one launch.
+// Returns GPK_OK with *used = 0 when the shape is not served here (the caller then runs the recursion).
+int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used) {
+  *used = 0;
+  if (!h->ptile || Np > h->ptile_max_np || Np < 2 * TS) return GPK_OK;
+  if (((uintptr_t)A % 128) != 0 || (lda % 16) != 0 || ((uintptr_t)winv % 128) != 0) return GPK_OK;
+  const int nt = (int)(Np / TS);
+  const int nb = h->batch;
+  const long long ntasks = (long long)nt * (nt + 1) / 2 * nb;
+  const size_t ctrl_ints = 16 + (size_t)nb * nt;
+  if (ntasks >= (1ll << 30) || ctrl_ints > GPK_PTILE_CTRL_INTS) return GPK_OK;
+  if (!h->d_ptile) {
+    GPK_CHECK_HIP(h, hipSetDevice(h->device));
+    GPK_CHECK_HIP(h, hipMalloc((void**)&h->d_ptile, GPK_PTILE_CTRL_INTS * sizeof(int)));
+    int cus = 0;
+    GPK_CHECK_HIP(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    h->ptile_slots = 2 * (cus > 0 ? cus : 256);
+  }
+  const long long sA = gpk_bstride(h, A), sW = gpk_bstride(h, winv);
+  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_ptile, 0, ctrl_ints * sizeof(int), h->stream));
+  // the part of winv above the block diagonal is never written by the kernel: the tile GEMMs that use winv read whole tiles
+  for (int b = 0; b < nb; ++b)
+    GPK_CHECK_HIP(h, hipMemsetAsync((char*)winv + b * sW, 0, (size_t)Np * TS * sizeof(double), h->stream));
+  PTParams p;
+  p.A = A; p.lda = lda; p.strideA = sA;
+  p.winv = winv; p.strideW = sW;
+  p.info = h->d_info; p.row0 = row0;
+  p.nt = nt; p.batch = nb; p.ntasks = (int)ntasks;
+  p.ctrl = h->d_ptile;
+  p.trace = nullptr;
+  if (const char* tp = getenv("GPK_PTILE_TRACE")) {        // debugging aid: per-task time stamps to the file named there
+    void* ws = nullptr;
+    GPK_TRY(gpk_scratch(h, (size_t)ntasks * 16 * sizeof(long long), &ws));
+    GPK_CHECK_HIP(h, hipMemsetAsync(ws, 0, (size_t)ntasks * 16 * sizeof(long long), h->stream));
+    p.trace = (long long*)ws;
+    h->ptile_trace_path = tp;
+    h->ptile_trace_n = ntasks;
+  }
+  const unsigned grid = (unsigned)(ntasks < h->ptile_slots ? ntasks : h->ptile_slots);
+  hipLaunchKernelGGL(ptile_potrf_kernel, dim3(grid), dim3(NT), 0, h->stream, p);
+  GPK_LAUNCH_CHECK(h);
+  *used = 1;
+  return GPK_OK;
+}
+
+// after the stream has been synchronised: did the launch give up?
+int gpk_potrf_ptile_check(gpk_handle h) {
+  if (!h->ptile_trace_path.empty() && h->scratch) {
+    std::vector<long long> t((size_t)h->ptile_trace_n * 16);
+    GPK_CHECK_HIP(h, hipMemcpy(t.data(), h->scratch, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(h->ptile_trace_path.c_str(), "w")) {
+      for (long long k = 0; k < h->ptile_trace_n; ++k) {
+        for (int c = 0; c < 16; ++c) fprintf(f, "%lld ", t[(size_t)k * 16 + c]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    h->ptile_trace_path.clear();
+  }
+  int ab = 0;
+  GPK_CHECK_HIP(h, hipMemcpy(&ab, h->d_ptile + 1, sizeof(int), hipMemcpyDeviceToHost));
+  if (ab != 0) {
+    h->err = "potrf: the one-launch factorisation timed out waiting for a tile (internal error)";
+    return GPK_HIP_ERROR;
+  }
+  return GPK_OK;
+}
