@@ -50,24 +50,38 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # writte
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n-train", type=int, default=65536)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 8; train: 2; lml: 5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 2; train: 1)")
+    ap.add_argument("--n-train", type=int, default=None, help="default: 65536; train: 10000; lml: 16384")
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra timing of the other variance paths")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "gram"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "gram", "train", "lml"],
                     help="c3 (default, the headline): mean+var for 10 000 queries per GPU per step, weak scaling; "
                          "c4: BASELINE configs[3] - 1 048 576 queries in total sharded over the GPUs, posterior means "
                          "only, RCCL all-gather of the means (strong scaling); gram: the fp64 RBF Gram build at N_train, "
-                         "row-sharded over the GPUs with no exchange (SURVEY 8e; strong scaling, GB/s)")
+                         "row-sharded over the GPUs with no exchange (SURVEY 8e; strong scaling, GB/s); "
+                         "train: the reference's offline-training workload (SimpleQuadrotorGP.train_gp(), N = 10 000, D = 10, "
+                         "P = 6, L-BFGS-B + 1 restart); lml: BASELINE configs[4] - LML + gradient of three fused per-axis ARD "
+                         "GPs at N = 16 384")
+    ap.add_argument("--replicate", default="broadcast", choices=["broadcast", "refit"],
+                    help="--gpus N > 1: how the ranks get the model - broadcast: rank 0 fits and broadcasts X, alpha and the "
+                         "split inverse factor over RCCL (the other ranks hold no factor); refit: every rank fits redundantly")
     ap.add_argument("--var-method", default="auto", choices=["auto", "inverse_split", "inverse_split2", "inverse", "solve"],
                     help="auto = inverse_split2: |L^-1 k*|^2 with the explicit inverse factor, one fused GEMM launch on the "
                          "16-bit matrix pipe, every fp32 operand as two round-to-nearest fp16 parts (represented to 2^-23), "
                          "three products per block, fp32 accumulation, operands from L2 straight into registers; "
                          "inverse_split: three exact bf16 parts, six products; inverse: the same launch on the exact-fp32 "
                          "MFMA; solve: blocked triangular solve chain")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    wl = args.workload
+    if args.steps is None:
+        args.steps = {"train": 2, "lml": 5}.get(wl, 8)
+    if args.warmup is None:
+        args.warmup = {"train": 1}.get(wl, 2)
+    if args.n_train is None:
+        args.n_train = {"train": 10000, "lml": 16384}.get(wl, 65536)
+    return args
 
 
 def launch_ranks(args):
@@ -269,6 +283,220 @@ def bench_gram(args, be, rank, world, use_dist, ranks_seen):
         dist.destroy_process_group()
 
 
+def synthetic_flight_problem(N, D=10, P=6, seed=7):
+    """Flight-like rows for the training workload (same generator as oracle.gp_oracle.synthetic_flight_problem)."""
+    rng = np.random.default_rng(seed)
+    X = 0.6 * rng.standard_normal((N, D))
+    X[:, 2] -= 3.0
+    if D >= 10:
+        X[:, 9] *= 1e-3
+    W = rng.standard_normal((6, P))
+    va = X[:, 3:9]
+    Y = 0.03 * np.sin(va @ W) - 0.01 * np.pad(va[:, :3] * np.abs(va[:, :3]), ((0, 0), (0, max(P - 3, 0))))[:, :P]
+    Y = Y + 0.005 * rng.standard_normal((N, P))
+    return X, Y
+
+
+def bench_train(args, be):
+    """--workload train: the reference's real offline-training job, src/px4/train_gp_offline.py:124-140 ->
+    SimpleQuadrotorGP(max_data_points=10000).train_gp() (src/px4/simple_gp.py:156-185: RBF(0.5) + White(0.1), alpha 1e-4,
+    normalize_y, L-BFGS-B + 1 restart) on N synthetic flight-like rows, D = 10, P = 6.  A step = one train_gp();
+    every LML + gradient evaluation of the optimiser (sklearn/_gpr.py:537-652) is timed."""
+    import contextlib
+    import torch
+    from unmanned_aerial_vehicles_amd import SimpleQuadrotorGP, _lib
+    from unmanned_aerial_vehicles_amd import gpr as gpr_mod
+    N, D, P = args.n_train, 10, 6
+    X, Y = synthetic_flight_problem(N)
+    evals = []
+    orig = gpr_mod.GaussianProcessRegressor._lml_on_device
+
+    def counted(self, theta, eval_gradient, dev=None):
+        t0 = time.perf_counter()
+        r = orig(self, theta, eval_gradient, dev)          # (ends with host reads of the reductions: synchronous)
+        evals.append((time.perf_counter() - t0, bool(eval_gradient)))
+        return r
+
+    gpr_mod.GaussianProcessRegressor._lml_on_device = counted
+    res = {}
+
+    def step():
+        np.random.seed(0)                                    # the restart point is drawn from the global RNG, as in the reference
+        gp = SimpleQuadrotorGP(max_data_points=10000)
+        gp.X_train.extend(X)
+        gp.Y_train.extend(Y)
+        with contextlib.redirect_stdout(sys.stderr):        # (train_gp reports like the reference: stdout carries ONE line)
+            gp.train_gp()
+        assert gp.is_trained
+        res["gp"] = gp
+        return gp
+
+    try:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        evals.clear()
+        be.check(be.lib.gpk_timing(be.h, 1))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gpr_mod.GaussianProcessRegressor._lml_on_device = orig
+    ms = np.zeros(64)
+    n = C.c_int(0)
+    be.check(be.lib.gpk_kernel_times(be.h, _lib.GPK_TIMED_POTRF, ms.ctypes.data_as(_lib._dp), 64, C.byref(n)))
+    potrf_ms = float(np.mean(ms[: n.value])) if n.value else None
+    be.check(be.lib.gpk_timing(be.h, 0))
+    gm = res["gp"].gp_model
+    ge = [t for t, g in evals if g]
+    s_eval = float(np.mean(ge))
+    flops = float(N) ** 3                                    # potrf N^3/3 + inverse factor N^3/3 + W^T W N^3/3 (SURVEY 8d, K6)
+    line = {
+        "metric": "offline GP training wall time: SimpleQuadrotorGP.train_gp() (L-BFGS-B + 1 restart, LML + analytic gradient "
+                  "per evaluation) on N_train rows, D=10, P=6",
+        "value": dt / args.steps, "unit": "s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic flight-like rows (bench.synthetic_flight_problem), random restart seeded",
+        "config": {"workload": f"train: N_train={N}, D={D}, P={P}, kernel RBF(0.5)+White(0.1), alpha=1e-4, normalize_y, "
+                               "n_restarts_optimizer=1 (src/px4/train_gp_offline.py:124-140, simple_gp.py:156-185)"},
+        "lml_grad_evaluations_per_train": len(ge) / args.steps,
+        "s_per_lml_grad_evaluation": s_eval, "s_per_lml_grad_evaluation_min": float(np.min(ge)),
+        "potrf_ms": potrf_ms,
+        "kernel": str(gm.kernel_), "lml": float(gm.log_marginal_likelihood_value_),
+        "roofline": {"bound": "mfma", "achieved": flops / s_eval / 1e12, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / s_eval / 1e12 / MFMA_F64_PEAK_TF, "traffic": None,
+                     "what": "one LML + gradient evaluation = N^3 fp64 flops (factor, inverse factor, K^-1 = W^T W; SURVEY 8d "
+                             "K6) over its wall time, host reductions and Gram build included"},
+        "peak_hbm_bytes_per_rank": int(torch.cuda.max_memory_allocated(be.device)),
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_train_baseline(N)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_train_baseline(n_full, n_sample=2000):
+    """scikit-learn (the library the reference's train_gp() calls) on the same generator at a bounded N; the N^3
+    extrapolation to n_full is labelled as such."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import warnings
+        from sklearn.gaussian_process import GaussianProcessRegressor as SkGPR
+        from sklearn.gaussian_process.kernels import RBF as SkRBF, WhiteKernel as SkWhite
+    except ImportError as e:
+        return {"skipped": repr(e)}
+    X, Y = synthetic_flight_problem(n_sample)
+    n_eval = [0]
+    orig = SkGPR.log_marginal_likelihood
+
+    def counted(self, *a, **k):
+        n_eval[0] += 1
+        return orig(self, *a, **k)
+
+    SkGPR.log_marginal_likelihood = counted
+    try:
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g = SkGPR(kernel=SkRBF(0.5) + SkWhite(0.1), alpha=1e-4, normalize_y=True, n_restarts_optimizer=1).fit(X, Y)
+        dt = time.perf_counter() - t0
+    finally:
+        SkGPR.log_marginal_likelihood = orig
+    scale = (n_full / n_sample) ** 3
+    return {"value": dt * scale, "unit": "s", "cores": cores, "kind": "reference", "basis": "extrapolated",
+            "rule": "measured seconds at the sample size x (N_train / sample N_train)^3",
+            "measured_seconds": dt, "measured_at_n_train": n_sample, "evaluations": n_eval[0],
+            "s_per_evaluation_measured": dt / max(n_eval[0], 1), "kernel": str(g.kernel_),
+            "sample": f"scikit-learn GaussianProcessRegressor(RBF+White, n_restarts_optimizer=1).fit at N_train={n_sample} "
+                      f"({dt:.1f} s, {n_eval[0]} evaluations, {cores} threads), N^3-extrapolated to N_train={n_full}"}
+
+
+def bench_lml(args, be):
+    """--workload lml: BASELINE configs[4] (C5) - LML + analytic gradient of three per-axis ARD GPs on shared inputs as ONE
+    fused launch chain (sklearn/_gpr.py:537-652 per model; src/px4/gp_trainer.py:163-179).  A step = one evaluation of all
+    three models.  `roofline`: the chain's N^3 fp64 flops per model against the fp64 matrix peak; `roofline_grad_kernel`: the
+    streaming pass over K^-1 (`lml_grad_kernel`) against HBM, its duration from the library's event brackets."""
+    import torch
+    from unmanned_aerial_vehicles_amd import BatchedARDGP, _lib
+    N, D, B = args.n_train, 9, 3
+    X, Y, _ = synthetic_problem(N, 1)
+    ls = 2.0 * (1.0 + 0.1 * np.arange(D))
+    bg = BatchedARDGP(length_scale=ls, noise_level=0.1, alpha=1e-4, normalize_y=True, optimizer=None).fit(X, Y)
+    th = np.array(bg.thetas)
+    for _ in range(max(args.warmup, 1)):
+        lml, grad = bg.log_marginal_likelihood(th, eval_gradient=True, fused=True)
+    torch.cuda.synchronize()
+    fbe = bg._fs["be"]
+    fbe.check(fbe.lib.gpk_timing(fbe.h, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lml, grad = bg.log_marginal_likelihood(th, eval_gradient=True, fused=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    def times(tag):
+        ms = np.zeros(64)
+        n = C.c_int(0)
+        fbe.check(fbe.lib.gpk_kernel_times(fbe.h, tag, ms.ctypes.data_as(_lib._dp), 64, C.byref(n)))
+        return ms[: n.value].copy()
+
+    grad_ms, potrf_ms = times(_lib.GPK_TIMED_GRAD), times(_lib.GPK_TIMED_POTRF)
+    fbe.check(fbe.lib.gpk_timing(fbe.h, 0))
+    assert len(grad_ms) >= B and np.isfinite(lml).all() and np.isfinite(grad).all()
+    step_s = dt / args.steps
+    flops = B * float(N) ** 3
+    Np = (N + 127) // 128 * 128
+    gk = float(np.mean(grad_ms)) * 1e-3
+    alg_bytes = 2.0 * N * N * 8                               # SURVEY 8(d), K6: one streaming pass, 2 N^2 s bytes
+    issued_bytes = Np * (Np + 128) / 2 * 8                    # what the kernel reads: the lower tiles of K^-1 (K is recomputed)
+    line = {
+        "metric": "LML + gradient evaluations/s, three per-axis ARD GPs fused into one launch chain (BASELINE configs[4])",
+        "value": B / step_s, "unit": "GP evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (SURVEY 8d generator), ARD l_d = 2.0 (1 + 0.1 d), noise 0.1, jitter 1e-4",
+        "config": {"workload": f"C5: N_train={N}, D={D}, B={B} single-output ARD GPs on shared inputs, LML + gradient"},
+        "roofline": {"bound": "mfma", "achieved": flops / step_s / 1e12, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / step_s / 1e12 / MFMA_F64_PEAK_TF, "traffic": None,
+                     "what": "B x N^3 fp64 flops (factor + inverse factor + W^T W per model) over the step's wall time"},
+        "roofline_grad_kernel": {"kernel": "lml_grad_kernel", "bound": "hbm", "achieved": alg_bytes / gk / 1e9,
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / gk / 1e9 / HBM_PEAK_GBPS,
+                                 "algorithmic_bytes_per_launch": alg_bytes, "issued_bytes_per_launch": issued_bytes,
+                                 "issued_GBps": issued_bytes / gk / 1e9, "ms_per_launch": gk * 1e3,
+                                 "launches_averaged": int(len(grad_ms)), "traffic": None},
+        "potrf_ms_all_models_one_launch": float(np.mean(potrf_ms)) if len(potrf_ms) else None,
+        "lml": [float(v) for v in lml],
+        "peak_hbm_bytes_per_rank": int(torch.cuda.max_memory_allocated(be.device)),
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_lml_baseline(N)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_lml_baseline(n_full, n_sample=2048):
+    """scikit-learn's own LML + gradient (one ARD model) on a bounded sample, N^3-extrapolated (labelled)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        from sklearn.gaussian_process import GaussianProcessRegressor as SkGPR
+        from sklearn.gaussian_process.kernels import RBF as SkRBF, ConstantKernel as SkC, WhiteKernel as SkWhite
+    except ImportError as e:
+        return {"skipped": repr(e)}
+    X, Y, _ = synthetic_problem(n_sample, 1)
+    ls = 2.0 * (1.0 + 0.1 * np.arange(9))
+    kern = SkC(1.0, "fixed") * SkRBF(ls, (0.1, 10.0)) + SkWhite(0.1, (1e-5, 1e1))
+    g = SkGPR(kernel=kern, alpha=1e-4, normalize_y=True, optimizer=None).fit(X, Y[:, 0])
+    t0 = time.perf_counter()
+    g.log_marginal_likelihood(g.kernel_.theta, eval_gradient=True)
+    dt = time.perf_counter() - t0
+    scale = (n_full / n_sample) ** 3
+    return {"value": 1.0 / (dt * scale), "unit": "GP evaluations/s", "cores": cores, "kind": "reference",
+            "basis": "extrapolated", "rule": "measured seconds at the sample size x (N_train / sample N_train)^3",
+            "measured_seconds": dt, "measured_at_n_train": n_sample,
+            "sample": f"scikit-learn log_marginal_likelihood(theta, eval_gradient=True) of one ARD model at N_train={n_sample} "
+                      f"({dt:.2f} s, {cores} threads), N^3-extrapolated to N_train={n_full}"}
+
+
 def main():
     args = parse_args()
     # (BENCH_FORCE_LAUNCH=1 takes the same parent -> torch.distributed.run -> rank route with one rank: the way to
@@ -322,6 +550,10 @@ def main():
     be = get_backend(local_rank)
     if args.workload == "gram":
         return bench_gram(args, be, rank, world, use_dist, ranks_seen)
+    if args.workload in ("train", "lml"):          # single-GPU workloads (the factorisation does not shard: "replicas only")
+        if world != 1:
+            raise SystemExit(f"--workload {args.workload} runs on one GPU")
+        return bench_train(args, be) if args.workload == "train" else bench_lml(args, be)
     c4 = args.workload == "c4"
     if c4:
         args.queries = (1 << 20) // world          # strong scaling: the 1 M queries are split over the ranks
@@ -341,67 +573,98 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- fit (set-up, timed separately)
-    dev = DeviceGP(X, Yn, be)
-    dev.timing(True)
-    dev.gram(ls, sf2, noise + jitter)            # warm-up of the Gram kernel + allocation
-    torch.cuda.synchronize()
-    for _ in range(6):
-        dev.gram(ls, sf2, noise + jitter)
-    gram_times = dev.kernel_times(_lib.GPK_TIMED_GRAM)[-6:] * 1e-3     # HIP events around the Gram kernel launches
-    gram_s = float(np.mean(gram_times))                                 # the average (what a rocprofv3 --stats row shows)
-    gram_bytes = dev.Np * dev.Np * 8 + N * D * 8          # N^2 s + N D s (s = 8)
-    info = C.c_int(0)
-    t0 = time.perf_counter()
-    be.check(be.lib.gpk_potrf(be.h, C.c_void_p(dev.K.data_ptr()), dev.Np, dev.Np, C.c_void_p(dev.winv.data_ptr()),
-                              C.byref(info)))
-    torch.cuda.synchronize()
-    potrf_s = time.perf_counter() - t0
-    dev.factored = True
+    # Multi-GPU: the model is REPLICATED.  --replicate broadcast (default for mean + variance serving): rank 0 fits and
+    # broadcasts what fp32 serving needs - X, alpha, the split inverse factor + scales (17 GB at N = 65 536, RCCL over
+    # xGMI) - the other ranks never hold L or the fp64 inverse factor; --replicate refit: every rank
+    # fits redundantly (deterministic, no communication).
     use_w = not c4 and method in ("inverse", "inverse_split", "inverse_split2")
-    if use_w:
-        # the inverse factor (34 GB) and its scratch come from torch's caching allocator: map them once outside the
-        # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
-        warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64),
-                be.empty((dev.Np, dev.Np), torch.float32), be.empty((dev.Np * dev.Np * 4,), torch.uint8)]
-        del warm
+    by_broadcast = world > 1 and args.replicate == "broadcast" and method == "inverse_split2" and not c4
+
+    def fit_model():
+        dev = DeviceGP(X, Yn, be)
+        dev.timing(True)
+        dev.gram(ls, sf2, noise + jitter)            # warm-up of the Gram kernel + allocation
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    trtri_s = None
-    if use_w:
-        dev.inverse_factor(False)                  # W = L^-1 on the fp64 MFMA (N^3/3 flops) ...
+        for _ in range(6):
+            dev.gram(ls, sf2, noise + jitter)
+        gram_times = dev.kernel_times(_lib.GPK_TIMED_GRAM)[-6:] * 1e-3     # HIP events around the Gram kernel launches
+        gram_s = float(np.mean(gram_times))                                 # the average (what a rocprofv3 --stats row shows)
+        gram_bytes = dev.Np * dev.Np * 8 + N * D * 8          # N^2 s + N D s (s = 8)
+        info = C.c_int(0)
+        t0 = time.perf_counter()
+        be.check(be.lib.gpk_potrf(be.h, C.c_void_p(dev.K.data_ptr()), dev.Np, dev.Np, C.c_void_p(dev.winv.data_ptr()),
+                                  C.byref(info)))
         torch.cuda.synchronize()
-        trtri_s = time.perf_counter() - t0
-        if method == "inverse_split":
-            dev.split_inverse_factor()             # ... served as three exact bf16 parts per entry (6 bytes)
-        elif method == "inverse_split2":
-            dev.split2_inverse_factor()            # ... served as two fp16 parts per entry (4 bytes)
+        potrf_s = time.perf_counter() - t0
+        dev.factored = True
+        if use_w:
+            # the inverse factor (34 GB) and its scratch come from torch's caching allocator: map them once outside the
+            # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
+            warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64),
+                    be.empty((dev.Np, dev.Np), torch.float32), be.empty((dev.Np * dev.Np * 4,), torch.uint8)]
+            del warm
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trtri_s = None
+        if use_w:
+            dev.inverse_factor(False)                  # W = L^-1 on the fp64 MFMA (N^3/3 flops) ...
+            torch.cuda.synchronize()
+            trtri_s = time.perf_counter() - t0
+            if method == "inverse_split":
+                dev.split_inverse_factor()             # ... served as three exact bf16 parts per entry (6 bytes)
+            elif method == "inverse_split2":
+                dev.split2_inverse_factor()            # ... served as two fp16 parts per entry (4 bytes)
+            else:
+                dev.inverse_factor(True)               # ... served as an fp32 copy
+        elif not c4:
+            dev._f32_factor()                          # fp32 copies of L / leaf inverses
+        torch.cuda.synchronize()
+        prep_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        dev.solve_alpha()                              # two launches through W when it exists, else the solve chain
+        torch.cuda.synchronize()
+        alpha_s = time.perf_counter() - t0
+        dev._f32_data()
+        torch.cuda.synchronize()
+        fit = {"n_train": N, "dtype": "f64",
+               "gram_ms": gram_s * 1e3, "gram_ms_min_avg_max": [float(gram_times.min() * 1e3), gram_s * 1e3, float(gram_times.max() * 1e3)],
+               "gram_launches_timed": int(len(gram_times)), "gram_GBps": gram_bytes / gram_s / 1e9,
+               "gram_frac_of_hbm_peak": gram_bytes / gram_s / 1e9 / HBM_PEAK_GBPS,
+               "cholesky_s": potrf_s, "cholesky_GFLOPs": N ** 3 / 3.0 / potrf_s / 1e9,
+               "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
+               "alpha_solve_ms": alpha_s * 1e3,
+               "variance_prep": "none (means only)" if c4 else
+                                {"inverse_split": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + exact bf16x3 split",
+                                 "inverse_split2": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp16x2 split",
+                                 "inverse": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy",
+                                 "solve": "fp32 copy of L"}[method],
+               "variance_prep_s": prep_s, "trtri_s": trtri_s,
+               "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None,
+               "replicated_per_rank": world > 1}
+        return dev, fit
+
+    if by_broadcast:
+        from unmanned_aerial_vehicles_amd.sharded import broadcast_state
+        dev, fit = fit_model() if rank == 0 else (None, None)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        meta, tens = dev.serving_state() if rank == 0 else (None, None)
+        meta, tens = broadcast_state(meta, tens, DeviceGP.SERVING_TENSORS, 0, None,
+                                     make_empty=lambda shape, dt: be.empty(shape, dt))
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_s = time.perf_counter() - t0
+        if rank != 0:
+            dev = DeviceGP.from_serving_state(meta, tens, be)
+            dev._f32_data()
         else:
-            dev.inverse_factor(True)               # ... served as an fp32 copy
-    elif not c4:
-        dev._f32_factor()                          # fp32 copies of L / leaf inverses
-    torch.cuda.synchronize()
-    prep_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    dev.solve_alpha()                              # two launches through W when it exists, else the solve chain
-    torch.cuda.synchronize()
-    alpha_s = time.perf_counter() - t0
-    dev._f32_data()
-    torch.cuda.synchronize()
-    fit = {"n_train": N, "dtype": "f64",
-           "gram_ms": gram_s * 1e3, "gram_ms_min_avg_max": [float(gram_times.min() * 1e3), gram_s * 1e3, float(gram_times.max() * 1e3)],
-           "gram_launches_timed": int(len(gram_times)), "gram_GBps": gram_bytes / gram_s / 1e9,
-           "gram_frac_of_hbm_peak": gram_bytes / gram_s / 1e9 / HBM_PEAK_GBPS,
-           "cholesky_s": potrf_s, "cholesky_GFLOPs": N ** 3 / 3.0 / potrf_s / 1e9,
-           "cholesky_frac_of_f64_mfma_peak": N ** 3 / 3.0 / potrf_s / 1e12 / MFMA_F64_PEAK_TF,
-           "alpha_solve_ms": alpha_s * 1e3,
-           "variance_prep": "none (means only)" if c4 else
-                            {"inverse_split": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + exact bf16x3 split",
-                             "inverse_split2": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp16x2 split",
-                             "inverse": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy",
-                             "solve": "fp32 copy of L"}[method],
-           "variance_prep_s": prep_s, "trtri_s": trtri_s,
-           "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None,
-           "replicated_per_rank": world > 1}
+            fit["replication"] = "broadcast"
+            fit["broadcast_s"] = bcast_s
+            fit["broadcast_bytes"] = int(sum(t.numel() * t.element_size() for t in tens.values()))
+    else:
+        dev, fit = fit_model()
+        fit["replication"] = "refit" if world > 1 else "none (one rank)"
 
     # ---------------------------------------------------------------- the timed hot path
     kss = sf2 + noise
@@ -614,6 +877,11 @@ def main():
         except Exception as e:  # noqa: BLE001 - an extra must never take the headline down
             extras["error"] = repr(e)
 
+    peak_all = [int(torch.cuda.max_memory_allocated(be.device))]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, peak_all[0])
+        peak_all = [int(v) for v in gathered]
     if rank == 0:
         total_pred = float(M) * world * args.steps
         line = {
@@ -639,11 +907,14 @@ def main():
                                        "is below 2^-22 |a b|; measured error equal to the exact-fp32 MFMA launch's: checked under "
                                        "\"parity\" and, for all three fp32 forms, under \"extras\")"
                                        if (method == "inverse_split2" and not c4) else "")),
-                       "parallelism": f"query-sharded x{world}, model replicated (every rank fits redundantly)" +
+                       "parallelism": f"query-sharded x{world}, model replicated (" +
+                                      ("rank 0 fits, RCCL broadcast of X, alpha and the split inverse factor" if by_broadcast
+                                       else "every rank fits redundantly") + ")" +
                                       ((", RCCL all-gather of the means" if c4 else ", RCCL all-gather of [mean|var]")
                                        if use_dist else "")},
             "roofline": roof,
             "peak_hbm_bytes_per_rank": int(torch.cuda.max_memory_allocated(be.device)),
+            "peak_hbm_bytes_all_ranks": peak_all,
             "parity": parity,
             "fit": fit,
             "host_api": host_api,
@@ -653,9 +924,29 @@ def main():
             cb = cpu_baseline(n_full=N)
             try:
                 full = cpu_full_size_predict(dev, X, y_mean, y_std, dev.alpha_host(), ls, noise)
-                if "mean" in full:                                 # the CPU result doubles as one more parity check
-                    mg = dev.predict_mean_dev(full["Xq"], y_mean, y_std, "float64").cpu().numpy()
-                    full["gpu_fp64_mean_max_rel_err_vs_cpu"] = float(np.max(np.abs(mg - full["mean"])) / np.max(np.abs(full["mean"])))
+                if "mean" in full:
+                    # the CPU result doubles as a parity check AT THE HEADLINE SIZE against scikit-learn itself
+                    # (`_gpr.py:441-494` on the same factor): posterior mean and standard deviation of the fp64 kernels
+                    # (bar 1e-8) and of the timed fp32 serving call (bars 1e-4 / 1e-3) on the same 200 queries
+                    Xq_t = torch.as_tensor(full["Xq"], device=be.device, dtype=torch.float64)
+                    mg = dev.predict_mean_dev(Xq_t, y_mean, y_std, "float64").cpu().numpy()
+                    vg = dev.predict_var_dev(Xq_t, kss, 0.0, "float64", "solve")
+                    sg = torch.sqrt(vg[:, None] * ystd2[None, :]).cpu().numpy()
+                    o32 = dev.predict_packed_dev(Xq_t.float(), y_mean, y_std, kss, 0.0, "float32", method).double().cpu().numpy()
+                    ref_m, ref_s = full["mean"], full["std"]
+                    rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))          # noqa: E731
+                    vs = {"queries": int(ref_m.shape[0]), "n_train": N,
+                          "fp64_mean_max_rel_err": rel(mg, ref_m),
+                          "fp64_std_max_rel_err": float(np.max(np.abs(sg - ref_s) / ref_s)), "fp64_tol": 1e-8,
+                          "fp32_mean_max_rel_err": rel(o32[:, :P], ref_m),
+                          "fp32_std_max_rel_err": float(np.max(np.abs(np.sqrt(o32[:, P:]) - ref_s) / ref_s)),
+                          "fp32_mean_tol": 1e-4, "fp32_std_tol": 1e-3}
+                    vs["ok"] = bool(vs["fp64_mean_max_rel_err"] < 1e-8 and vs["fp64_std_max_rel_err"] < 1e-8 and
+                                    vs["fp32_mean_max_rel_err"] < 1e-4 and vs["fp32_std_max_rel_err"] < 1e-3)
+                    line["parity"]["vs_sklearn_at_n_train"] = vs
+                    assert vs["ok"], f"GPU predictions disagree with scikit-learn at N_train={N}: {vs}"
+                    full["gpu_fp64_mean_max_rel_err_vs_cpu"] = vs["fp64_mean_max_rel_err"]
+                    full["gpu_fp64_std_max_rel_err_vs_cpu"] = vs["fp64_std_max_rel_err"]
                     for k in ("mean", "std", "Xq"):
                         full.pop(k)
                 cb["measured_at_n_train"] = full
@@ -665,6 +956,8 @@ def main():
                     cb["sample"] = (f"scikit-learn GaussianProcessRegressor.predict(return_std=True) of {full['queries']} queries at "
                                     f"N_train={N} on a regressor carrying the factor computed on the GPU (downloaded, untimed): "
                                     f"{full['predict_seconds']:.1f} s on {cb['cores']} threads")
+            except AssertionError:
+                raise
             except Exception as e:  # noqa: BLE001
                 cb["measured_at_n_train"] = {"skipped": repr(e)}
             line["cpu_baseline"] = cb

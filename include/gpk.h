@@ -63,7 +63,8 @@ GPK_API int64_t gpk_padded(int64_t n);
 /* ---- measurement aid -----------------------------------------------------------------------------------
  * gpk_timing(h, 1): from now on the handle brackets its dominant launches with HIP events recorded on the
  * handle's stream - tag GPK_TIMED_K5: the one GEMM launch of gpk_predict_var_inv / gpk_predict_var_inv_split
- * (V = W K*^T with the column-norm epilogue); tag GPK_TIMED_GRAM: the Gram kernel of gpk_gram - and keeps the
+ * (V = W K*^T with the column-norm epilogue); tag GPK_TIMED_GRAM: the Gram kernel of gpk_gram; tag GPK_TIMED_GRAD: the
+ * streaming pass of gpk_lml_grad over K^-1; tag GPK_TIMED_POTRF: the launches of one gpk_potrf - and keeps the
  * last 64 pairs.  gpk_kernel_times synchronises the stream and returns the elapsed milliseconds of the bracketed
  * launches with that tag still in the ring, oldest first (*n_out of them, at most max_n).  bench.py uses it to
  * report the dominant kernel's duration over exactly the timed steps; rocprofv3's kernel trace of the same run is
@@ -72,10 +73,11 @@ GPK_API int64_t gpk_padded(int64_t n);
  * GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle:
  * "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = the tallest of the 512 / 256 / 128 x 128 tiles that still comes in at
  * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256",
- * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np".  Used by the A/B timings and by the tests that pin a fast path
+ * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
+ * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain).  Used by the A/B timings and by the tests that pin a fast path
  * to its plain form.                                                                                                */
 GPK_API int gpk_set_option(gpk_handle h, const char* name, int value);
-enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2 };
+enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2, GPK_TIMED_GRAD = 3, GPK_TIMED_POTRF = 4 };
 GPK_API int gpk_timing(gpk_handle h, int enable);
 GPK_API int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out);
 
@@ -247,6 +249,11 @@ GPK_API int gpk_predict_var_inv_split(gpk_handle h, const float* X, int64_t N, i
  * (profiles/r02_fp32_variance_forms_accuracy.log).  var: dev double[Mp].  D <= 16.
  * Replaces the same reference lines as gpk_predict_var (sklearn/gaussian_process/_gpr.py:454-485).                  */
 GPK_API int gpk_split2_rows(gpk_handle h, const float* W, int64_t n, int64_t ld, float* scales, void* dst);
+/* gpk_split2_rows_f64: the same scales and parts straight from the fp64 inverse factor (gpk_trtri output, dev n x ld doubles):
+ * every entry is rounded to fp32 on the fly exactly as gpk_tril_to_f32 would have stored it, so the result is bit-identical
+ * on the lower tiles while the fp32 copy (17 GB at N = 65 536) and two passes over it are gone; the 16-column blocks right of
+ * a row's diagonal tile - which the variance launch never reads - are left unwritten.                                    */
+GPK_API int gpk_split2_rows_f64(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst);
 GPK_API int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
                                        const void* W2, const float* w_scales, int64_t Np, const float* Xq, int64_t M,
                                        double kss, double floor_, void* work2, double* var);

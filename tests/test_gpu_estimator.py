@@ -1,6 +1,7 @@
 """GPU parity tests of the drop-in surfaces (estimator seam, model seam, package GP, per-output
 ARD GPs) against the golden fixtures produced by scikit-learn 1.7.2 and the reference's own
 modules.  Bar for fp64 at fixed hyper-parameters: 1e-8 relative (BASELINE.json north_star)."""
+import os
 import pickle
 
 import numpy as np
@@ -677,3 +678,35 @@ def test_batched_fused_lml_odd_training_size(csv_data):
     np.random.seed(1)
     res = GPTrainer().train_gp_models(csv_data["X10"][:302], csv_data["Y6"][:302], n_restarts_optimizer=0)
     assert len(res) == 6 and all(np.isfinite(r["log_marginal_likelihood"]) for r in res.values())
+
+
+def test_model_evaluator_on_the_reference_grid(csv_data, tmp_path):
+    """§8(f) batched-predict caller `GPModelEvaluator` (src/px4/gp_evaluation.py:54-549): the reference class on a pickle of
+    ITS trained KA3 model gave tests/golden/evaluator_ref.npz; the same model (the reference's final theta) trained here,
+    pickled in the reference's container layout, loaded from the file and predicted on the seeded 2 300-row grid as ONE
+    batched call must give the reference's arrays to 1e-8."""
+    import pickle
+    from unmanned_aerial_vehicles_amd.evaluate import GPModelEvaluator
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "evaluator_ref.npz"))
+    ls, noise = np.exp(ref["theta"])
+    g = _gpr(ls, noise).fit(csv_data["X10"], csv_data["Y6"])
+    assert abs(g.log_marginal_likelihood_value_ - float(ref["lml"])) < 1e-9 * abs(float(ref["lml"]))
+    path = tmp_path / "gp_model_latest.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"gp_model": g, "training_count": 1000, "data_points_used": 1000, "timestamp": "20251129_170501",
+                     "is_trained": True}, f)
+    ev = GPModelEvaluator(str(path))
+    assert ev.mode == str(ref["mode"]) and ev.n_features == int(ref["n_features"])
+    calls = []
+    orig = ev.gp_model.predict
+    ev.gp_model.predict = lambda X, return_std=False: (calls.append(len(X)), orig(X, return_std=return_std))[1]
+    res = ev.run_complete_evaluation()
+    assert calls == [2300]                                               # one batched call (K4 + K5), not 2300
+    assert list(res["predictions"]) == [str(n) for n in ref["pred_names"]]
+    p = res["predictions"]["output"]
+    for k in ("mean", "std", "upper", "lower"):
+        assert p[k].shape == ref[f"pred_output_{k}"].shape
+        assert relerr(p[k], ref[f"pred_output_{k}"]) < TOL, k
+    s = res["summary"]
+    assert abs(s["mean_uncertainty"] - float(ref["printed_mean_uncertainty"])) < 5.1e-5
+    assert abs(100 * s["high_confidence"] - float(ref["printed_high_pct"])) < 0.051

@@ -68,6 +68,27 @@ def _worker(rank, world, port, M, q):
         _, var_raw = ShardedPredictor(g2, dtype="float32", gated=False).predict_mean_var(Xq2)
         e_raw = np.max(np.abs(np.sqrt(var_raw.cpu().numpy()) - r_std) / r_std)
         ok = ok and e_m < 1e-4 and e_s < 1e-3 and e_raw > e_s
+        # replication by broadcast: only rank 0's estimator is used, the other ranks receive X, alpha and
+        # the split inverse factor and never hold L; the low variances of the low-noise model are recomputed on rank 0
+        for gm, Xt, rm, rs in ((g, Xq, ref_mean, ref_std), (g2, Xq2, r_mean, r_std)):
+            sp = ShardedPredictor(gm if rank == 0 else None, dtype="float32").replicate(0)
+            if rank != 0:
+                ok = ok and sp.gpr._dev.replica and sp.gpr._dev.K is None and "f64" not in sp.gpr._dev._Winv
+            mean, var = sp.predict_mean_var(Xt)
+            mean, var = mean.cpu().numpy(), var.cpu().numpy()
+            ok = ok and np.max(np.abs(mean - rm)) / np.max(np.abs(rm)) < 1e-4 and np.max(np.abs(np.sqrt(var) - rs) / rs) < 1e-3
+        # a replica built in this process serves bit-identically to the model it was taken from, and owns no factor
+        from unmanned_aerial_vehicles_amd.device import DeviceGP
+        meta, tens = g._dev.serving_state()
+        rep = DeviceGP.from_serving_state(meta, tens, g._dev.be)
+        a = g._dev.predict_packed_dev(Xq, g._y_train_mean, g._y_train_std, 1.1, 0.0, "float32")
+        b = rep.predict_packed_dev(Xq, g._y_train_mean, g._y_train_std, 1.1, 0.0, "float32")
+        ok = ok and torch.equal(a, b) and rep.fp32_mean_ok() == g._dev.fp32_mean_ok()
+        try:
+            rep.predict_var_dev(Xq[:4], 1.1, 0.0, "float64", rep._fp64_var_method())
+            ok = False
+        except RuntimeError:
+            pass
         one = torch.ones(1, device=torch.device("cuda", rank))
         dist.all_reduce(one)
         q.put((rank, bool(ok), int(one.item())))

@@ -347,3 +347,59 @@ print("EXIT", code)
 def json_line(s):
     import json
     return json.loads(s)
+
+
+def test_model_evaluator_grid_and_summary_vs_reference_fixture():
+    """`GPModelEvaluator` (src/px4/gp_evaluation.py:150-207, 503-549): the seeded physical test grid bit for bit, and the
+    summary numbers the reference printed for its own predictions on it (tests/golden/evaluator_ref.npz, make_golden_r4.py);
+    a stand-in estimator exercises both model-file layouts without a GPU."""
+    from unmanned_aerial_vehicles_amd.evaluate import GRID_COLUMNS, GPModelEvaluator
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "evaluator_ref.npz"))
+    grid = GPModelEvaluator.generate_physical_test_data(2000)
+    assert list(ref["grid_columns"]) == GRID_COLUMNS
+    assert np.array_equal(np.column_stack([grid[c] for c in GRID_COLUMNS]), ref["grid"])
+    pred = {"output": {k: ref[f"pred_output_{k}"] for k in ("mean", "std", "upper", "lower")}}
+    s = GPModelEvaluator.analyze_gp_performance(pred)
+    po = s["per_output"]["output"]
+    assert np.allclose([po["mean_pred"], po["sigma_avg"], po["sigma_max"]], ref["printed_output_stats"], atol=5.1e-5)
+    assert abs(s["mean_uncertainty"] - float(ref["printed_mean_uncertainty"])) < 5.1e-5
+    assert abs(s["max_uncertainty"] - float(ref["printed_max_uncertainty"])) < 5.1e-5
+    assert abs(s["p90_uncertainty"] - float(ref["printed_p90_uncertainty"])) < 5.1e-5
+    assert abs(100 * s["high_confidence"] - float(ref["printed_high_pct"])) < 0.051
+    assert abs(100 * s["medium_confidence"] - float(ref["printed_medium_pct"])) < 0.051
+    assert abs(100 * s["low_confidence"] - float(ref["printed_low_pct"])) < 0.051
+
+    class Fake:                                   # predict(X, return_std=True) -> (M, 2) means and stds
+        n_features_in_ = 10
+
+        def predict(self, X, return_std=False):
+            m = np.stack([X[:, 3], -X[:, 4]], axis=1)
+            return (m, 0.2 + 0.0 * m) if return_std else m
+
+    ev = GPModelEvaluator(model_data={"gp_model": Fake(), "training_count": 5, "is_trained": True})
+    assert ev.mode == "single" and ev.n_features == 10 and ev.training_stats["training_count"] == 5
+    out = ev.run_complete_evaluation()
+    p = out["predictions"]["output"]
+    assert p["mean"].shape == (4600,)                       # the reference flattens a multi-output estimator row-major
+    assert np.array_equal(p["mean"][0::2], grid["vx"]) and np.allclose(p["upper"] - p["lower"], 0.8)
+    assert out["summary"]["medium_confidence"] == 1.0
+
+    class Scaler:
+        scale_ = np.array([3.0])
+
+        def transform(self, X):
+            return X * 2.0
+
+        def inverse_transform(self, y):
+            return y * 3.0 + 1.0
+
+    class One:
+        def predict(self, X, return_std=False):
+            return X[:, 0], np.full(len(X), 0.5)
+
+    ev = GPModelEvaluator(model_data={"models": {"vx_residual": One()}, "scalers_input": {"vx_residual": Scaler()},
+                                      "scalers_output": {"vx_residual": Scaler()}})
+    p = ev.predict_on_test_data(grid)["vx_residual"]
+    assert ev.mode == "multi" and np.allclose(p["mean"], grid["x"] * 2.0 * 3.0 + 1.0) and np.allclose(p["std"], 1.5)
+    with pytest.raises(KeyError):
+        GPModelEvaluator(model_data={"something": 1})

@@ -16,7 +16,7 @@ GPK_F32, GPK_F64 = 0, 1
 GPK_OK, GPK_NOT_PD, GPK_BAD_ARG, GPK_HIP_ERROR = 0, 1, 2, 3
 GPK_TILE, GPK_MAX_D, GPK_MAX_P = 128, 64, 16
 GPK_HOST_MAX_M = 4096
-GPK_TIMED_K5, GPK_TIMED_GRAM = 1, 2
+GPK_TIMED_K5, GPK_TIMED_GRAM, GPK_TIMED_GRAD, GPK_TIMED_POTRF = 1, 2, 3, 4
 
 _vp, _i64, _int, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
 _dp = C.POINTER(C.c_double)
@@ -39,6 +39,7 @@ SIGNATURES = {
     "gpk_import": (_int, [_vp, _dp, _i64, _int, _dp, _dp, _int, _dp, _int, _dbl, _dbl, _dp, _dp]),
     "gpk_model_release": (_int, [_vp]),
     "gpk_split2_rows": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gpk_split2_rows_f64": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gpk_predict_var_inv_split2": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _vp, _vp]),
     "gpk_predict_mean_var_split2": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _dp, _vp, _vp, _i64, _vp, _i64,
                                            _dbl, _dbl, _vp, _vp, _dbl, _vp, _vp]),

@@ -27,9 +27,6 @@ constexpr int NB = 128;       // leaf size
 // C/D map row = (lane >> 4) + 4 reg is exactly the B-operand map of k-step reg).  Off-diagonal W
 // blocks are parked transposed in the (otherwise unused) upper triangle of the LDS image.
 // FACTOR == false: the block already holds a factor (imported model); only W is produced.
-#ifndef GPK_LEAF_SKIP
-#define GPK_LEAF_SKIP 0     // timing experiments only (tools/exp_leaf_time.sh): bit 0 skips P1, 1 P2, 2 P3, 3 the inverse; results are then wrong
-#endif
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int LSA = 130;   // LDS row stride of the 128 x 128 image
 constexpr int LSW = 18;    // row stride of the 16 x 16 diagonal inverses
@@ -95,7 +92,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
     const int c0 = 16 * jb;
     if (FACTOR) {
       // ---- P1: left-looking update of block column jb
-      if (jb > 0 && !(GPK_LEAF_SKIP & 1)) {
+      if (jb > 0) {
         for (int ib = jb + wave; ib < 8; ib += 4) {
           d4 acc;
 #pragma unroll
@@ -124,7 +121,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
     // Straight-line and branch-free (a failed pivot is handled by selects and reported once); the next pivot's
     // reciprocal -- v_rcp_f64 + two Newton steps, error ~1e-16, the loop-carried chain -- is issued right after the
     // one update it depends on.  Entries above the diagonal of the block rows are never read.
-    if (wave == 0 && !(GPK_LEAF_SKIP & 2)) {
+    if (wave == 0) {
       const int i = lane & 15;
       double u[16], x[16];
 #pragma unroll
@@ -204,7 +201,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
     __syncthreads();
     // ---- P3: the panel below the diagonal block, X = A W_jj^T (the solve x L_jj^T = a through the explicit
     // inverse), one 16 x 16 block per wave on the MFMA
-    if (FACTOR && !(GPK_LEAF_SKIP & 4)) {
+    if (FACTOR) {
       for (int ib = jb + 1 + wave; ib < 8; ib += 4) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(double* __restrict__ A0, long
   }
 
   // ---- inverse, block diagonal by block diagonal
-  for (int d = 1; d < ((GPK_LEAF_SKIP & 8) ? 1 : 8); ++d) {
+  for (int d = 1; d < 8; ++d) {
     for (int i = d + wave; i < 8; i += 4) {
       const int j = i - d;
       d4 S = {0.0, 0.0, 0.0, 0.0};
@@ -707,8 +704,11 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, doubl
   const int nb = h->batch;                         // batched mode: info receives one entry per problem
   GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, nb * sizeof(int), h->stream));
   int one_launch = 0;
-  GPK_TRY(gpk_potrf_ptile(h, A, Np, lda, winv, 0, &one_launch));
-  if (!one_launch) GPK_TRY(potrf_rec(h, A, lda, Np, winv, 0));
+  gpk_time_begin(h, GPK_TIMED_POTRF);
+  int rc = gpk_potrf_ptile(h, A, Np, lda, winv, 0, &one_launch);
+  if (rc == GPK_OK && !one_launch) rc = potrf_rec(h, A, lda, Np, winv, 0);
+  gpk_time_end(h);
+  GPK_TRY(rc);
   int hinfo_all[GPK_MAX_BATCH] = {0};
   GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo_all, h->d_info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
@@ -801,6 +801,7 @@ extern "C" int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t l
   return GPK_OK;
 }
 
+namespace {
 // zero the tiles right of each diagonal tile of W (GPK_ZERO_BAND_TILES - 1 of them): the K5 launch gives every
 // row of an 8-row super-tile the k-range of its longest row and relies on zeros beyond a row's own range
 __global__ void zero_band_kernel(double* __restrict__ W0, long long Np, long long ldw, long long strideW) {
@@ -810,6 +811,7 @@ __global__ void zero_band_kernel(double* __restrict__ W0, long long Np, long lon
   const long long j = j0 + (long long)blockIdx.y * 256 + threadIdx.x;
   if (j < j1) W[i * ldw + j] = 0.0;
 }
+}  // namespace
 
 extern "C" int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
                          int64_t ldw, double* work) {

@@ -178,8 +178,10 @@ extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, con
   GPK_TRY(gpk_scratch(h, (size_t)(nblocks + 1) * GW * sizeof(double), &ws));
   double* partial = (double*)ws;
   double* out = partial + (size_t)nblocks * GW;
+  gpk_time_begin(h, GPK_TIMED_GRAD);
   hipLaunchKernelGGL(lml_grad_kernel, dim3(nblocks), dim3(256), 0, h->stream, X, (long long)N, D, l, sf2, alpha, P,
                      Kinv, (long long)ldk, (long long)ntiles, partial);
+  gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(GW), dim3(256), 0, h->stream, (const double*)partial,
                      nblocks, out);

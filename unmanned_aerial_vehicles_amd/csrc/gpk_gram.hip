@@ -782,6 +782,7 @@ extern "C" int gpk_cross_gram_t(gpk_handle h, int dtype, const void* X, int64_t 
 
 // ---- row slab of the padded Gram matrix (multi-GPU build: every rank writes the rows it owns, no exchange) --------
 // diagonal of the slab's rows: sf2 + diag_add inside the data, 1 in the identity padding
+namespace {
 template <typename T>
 __global__ void slab_diag_kernel(T* __restrict__ K, long long ldk, long long row0, long long nrows_p, long long N,
                                  long long Np, T dval) {
@@ -790,6 +791,7 @@ __global__ void slab_diag_kernel(T* __restrict__ K, long long ldk, long long row
   const long long i = row0 + r;
   if (i < Np) K[r * ldk + i] = i < N ? dval : T(1);
 }
+}  // namespace
 
 extern "C" int gpk_gram_rows(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls, double sf2,
                              double diag_add, int64_t row0, int64_t nrows, void* Kslab, int64_t ldk) {

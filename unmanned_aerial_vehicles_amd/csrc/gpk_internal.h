@@ -43,7 +43,7 @@ struct gpk_context {
   int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
   int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
                              // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
-  int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 256 <= Np <= ptile_max_np (GPK_PTILE=0: recursion)
+  int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 512 <= Np <= ptile_max_np (GPK_PTILE=0: recursion)
   int ptile_max_np = 16384;
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU

@@ -393,7 +393,9 @@ __global__ __launch_bounds__(256, 1) void k5_direct_kernel(DParams p) {
 
   // ---- epilogue: per-column sums of squares of the tile (fp64), out[tile row][column]
   __shared__ double red[4 * 128];
-  const float alpha = 1.0f / (p.wscale[(row0 + 32 * AB * wave) >> 7] * p.kscale);     // powers of two: exact
+  // powers of two, each reciprocal exact; formed separately so that a large block scale times the K* scale cannot
+  // overflow on the way (absmax_to_scale_kernel also keeps block scales at or below 2^100)
+  const float alpha = (1.0f / p.wscale[(row0 + 32 * AB * wave) >> 7]) * (1.0f / p.kscale);
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     float s = 0.f;
@@ -447,6 +449,43 @@ __global__ __launch_bounds__(256) void tril_block_absmax_kernel(const float* __r
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out + (i >> 7), __float_as_uint(m));
 }
+// The same two kernels reading the fp64 inverse factor itself (gpk_trtri output): the fp32 value is formed on the fly,
+// (float)W_ij rounded to nearest - what gpk_tril_to_f32 would have stored - so scales and parts are bit-identical to the
+// route through an fp32 copy, which then need not exist (17 GB at N = 65 536).  Only the lower tiles are read; the 16-column
+// blocks right of a row's diagonal tile are not written (the variance launch stops at the diagonal tile).
+__global__ __launch_bounds__(256) void tril_block_absmax_f64_kernel(const double* __restrict__ A, long long n, long long lda,
+                                                                    unsigned* __restrict__ out) {
+  const long long i = blockIdx.x;
+  float m = 0.f;
+  for (long long jj = threadIdx.x; jj <= i; jj += 256) m = fmaxf(m, fabsf((float)A[i * lda + jj]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out + (i >> 7), __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void split2_f64_kernel(const double* __restrict__ src, long long n, long long ld,
+                                                          const float* __restrict__ scales, V16* __restrict__ dst) {
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long KB = n >> 4;
+  const long long kb = (long long)blockIdx.x * 4 + wave, rb = blockIdx.y;
+  if (kb >= KB || kb * 16 >= ((rb * 32) / 128 + 1) * 128) return;          // right of the diagonal tile: never read
+  const int r = lane & 31, h = lane >> 5;
+  const long long row = rb * 32 + r, col0 = kb * 16 + h * 8;
+  const float sc = scales[row >> 7];
+  const dv2* s2 = reinterpret_cast<const dv2*>(src + row * ld + col0);
+  const dv2 a = s2[0], b = s2[1], c = s2[2], d = s2[3];
+  const double v[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+  f16x8 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = (col0 + j <= row ? (float)v[j] : 0.f) * sc;
+    const _Float16 h0 = (_Float16)x;
+    p0[j] = h0;
+    p1[j] = (_Float16)(x - (float)h0);
+  }
+  V16* o = dst + ((rb * KB + kb) * 2) * 64 + lane;
+  o[0] = __builtin_bit_cast(V16, p0);
+  o[64] = __builtin_bit_cast(V16, p1);
+}
 __global__ void absmax_to_scale_kernel(unsigned* __restrict__ io, int nblk) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
@@ -455,7 +494,7 @@ __global__ void absmax_to_scale_kernel(unsigned* __restrict__ io, int nblk) {
   float s = 1.f;
   if (u != 0u && u < 0x7f800000u) {
     const int se = ((u & 0x7fffffu) == 0u ? 15 : 14) - e;          // largest power of two with s * max <= 2^15
-    s = __uint_as_float((unsigned)(min(max(se, -126), 127) + 127) << 23);
+    s = __uint_as_float((unsigned)(min(max(se, -126), 100) + 127) << 23);    // (<= 2^100: s times the K* scale stays finite)
   }
   reinterpret_cast<float*>(io)[b] = s;
 }
@@ -490,6 +529,25 @@ extern "C" int gpk_split2_rows(gpk_handle h, const float* W, int64_t n, int64_t 
   GPK_LAUNCH_CHECK(h);
   hipLaunchKernelGGL(split2_kernel, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)(n / 32)), dim3(256), 0, h->stream, W,
                      (long long)n, (long long)n, (long long)ld, (const float*)scales, (V16*)dst);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+extern "C" int gpk_split2_rows_f64(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, W && scales && dst, "split2_rows_f64: null pointer");
+  GPK_REQUIRE(h, n >= 128 && n % 128 == 0 && ld >= n && ld % 2 == 0 && n < (1ll << 24), "split2_rows_f64: n must be a multiple of 128");
+  GPK_REQUIRE(h, ((uintptr_t)W % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split2_rows_f64: buffers must be 16-byte aligned");
+  const int nblk = (int)(n / 128);
+  GPK_CHECK_HIP(h, hipMemsetAsync(scales, 0, nblk * sizeof(float), h->stream));
+  hipLaunchKernelGGL(tril_block_absmax_f64_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, W, (long long)n, (long long)ld,
+                     reinterpret_cast<unsigned*>(scales));
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(absmax_to_scale_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, h->stream,
+                     reinterpret_cast<unsigned*>(scales), nblk);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(split2_f64_kernel, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)(n / 32)), dim3(256), 0, h->stream, W,
+                     (long long)n, (long long)ld, (const float*)scales, (V16*)dst);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }

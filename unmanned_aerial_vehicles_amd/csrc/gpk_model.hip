@@ -331,17 +331,18 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
     GPK_LAUNCH_CHECK(h);
   }
   if (f32 && var && !m->W3) {
-    // fp32 serving form of K5: W as two fp16 parts per entry (the fp32 copy is only the source of the split)
-    float* Wf = nullptr;
-    GPK_CHECK_HIP(h, hipMalloc((void**)&Wf, (size_t)m->Np * m->Np * sizeof(float)));
-    int rc = gpk_tril_to_f32(h, m->W, m->Np, m->Np, Wf, m->Np);
-    if (rc == GPK_OK)
-      rc = (hipMalloc(&m->W3, (size_t)m->Np * m->Np * 4) == hipSuccess &&
-            hipMalloc((void**)&m->w_scales, (size_t)(m->Np / 128) * sizeof(float)) == hipSuccess) ? GPK_OK : GPK_HIP_ERROR;
-    if (rc == GPK_OK) rc = gpk_split2_rows(h, Wf, m->Np, m->Np, m->w_scales, m->W3);
-    if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
-    (void)hipFree(Wf);
-    GPK_TRY(rc);
+    // fp32 serving form of K5: W as two fp16 parts per entry, straight from the fp64 inverse factor (no fp32 copy).
+    // All or nothing: a failure leaves no half-built operand behind for the next call to trust.
+    int rc = (hipMalloc(&m->W3, (size_t)m->Np * m->Np * 4) == hipSuccess &&
+              hipMalloc((void**)&m->w_scales, (size_t)(m->Np / 128) * sizeof(float)) == hipSuccess) ? GPK_OK : GPK_HIP_ERROR;
+    if (rc != GPK_OK) h->err = "predict: out of device memory for the split inverse factor";
+    if (rc == GPK_OK) rc = gpk_split2_rows_f64(h, m->W, m->Np, m->Np, m->w_scales, m->W3);
+    if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) { rc = GPK_HIP_ERROR; h->err = "predict: split of the inverse factor failed"; }
+    if (rc != GPK_OK) {
+      if (m->W3) { (void)hipFree(m->W3); m->W3 = nullptr; }
+      if (m->w_scales) { (void)hipFree(m->w_scales); m->w_scales = nullptr; }
+      return rc;
+    }
   }
   // panel loop: <= 16384 queries and <= 4 GiB of K* per panel
   int64_t panel = (int64_t)((4ull << 30) / ((size_t)m->Np * es)) / GPK_TILE * GPK_TILE;

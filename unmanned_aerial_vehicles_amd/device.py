@@ -150,6 +150,7 @@ class DeviceGP:
         self._host_args = None   # predict_host: cached argument addresses
         self._amp = None         # fp32 mean gate: cached amplification estimate
         self._Kinv = None
+        self.replica = False     # True: a serving replica built by from_serving_state (no factor, no fp64 inverse factor)
 
     # ---- fit-side -------------------------------------------------------------------------
     def _ensure_K(self):
@@ -463,18 +464,62 @@ class DeviceGP:
         power-of-two scale per 128-row block, computed on the device): the operand of `method="inverse_split2"`."""
         torch = _torch()
         if "split2" not in self._Winv:
-            had_f32 = "f32" in self._Winv
-            Wf = self.inverse_factor(True)
             be = self.be
             scales = be.empty((self.Np // 128,), torch.float32)
             W2 = be.empty((self.Np * self.Np * 4,), torch.uint8)
-            with be.lock:
-                be.bind_stream()
-                be.check(be.lib.gpk_split2_rows(be.h, _p(Wf), self.Np, self.Np, _p(scales), _p(W2)))
+            if "f32" in self._Winv:              # an fp32 copy already exists (another variance form made it): split that
+                with be.lock:
+                    be.bind_stream()
+                    be.check(be.lib.gpk_split2_rows(be.h, _p(self._Winv["f32"]), self.Np, self.Np, _p(scales), _p(W2)))
+            else:                                # straight from the fp64 inverse factor: no fp32 copy, bit-identical parts
+                W = self.inverse_factor(False)
+                with be.lock:
+                    be.bind_stream()
+                    be.check(be.lib.gpk_split2_rows_f64(be.h, _p(W), self.Np, self.Np, _p(scales), _p(W2)))
             self._Winv["split2"] = (W2, scales)
-            if not had_f32:
-                self._Winv.pop("f32", None)
         return self._Winv["split2"]
+
+    # ---- replication by broadcast (multi-GPU serving, SURVEY.md 8(e): "broadcast once from rank 0") --------------------
+    SERVING_TENSORS = ("X", "alpha", "W2", "w_scales")
+
+    def serving_state(self):
+        """Everything a rank needs to SERVE this model in fp32 (posterior mean + variance through the fp16 x 2 variance
+        launch): the training inputs, alpha, the split inverse factor with its row-block scales (4 bytes per entry of the
+        lower tiles: 17 GB at N = 65 536) and the hyper-parameters - not L, not the fp64 inverse factor.  Returns
+        (meta dict of plain Python values, dict of device tensors named in SERVING_TENSORS)."""
+        assert self.factored and not self.replica
+        W2, w_scales = self.split2_inverse_factor()
+        meta = {"N": self.N, "D": self.D, "P": self.P, "Np": self.Np, "ls": np.asarray(self.ls, dtype=np.float64).tolist(),
+                "sf2": float(self.sf2), "shapes": {"X": (self.N, self.D), "alpha": (self.N, self.P),
+                                                   "W2": (self.Np * self.Np * 4,), "w_scales": (self.Np // 128,)},
+                "dtypes": {"X": "float64", "alpha": "float64", "W2": "uint8", "w_scales": "float32"}}
+        return meta, {"X": self.X, "alpha": self.alpha, "W2": W2, "w_scales": w_scales}
+
+    @classmethod
+    def from_serving_state(cls, meta, tensors, backend=None):
+        """A serving replica from `serving_state()` as received on another rank: fp32 mean and variance (and the fp64
+        mean) work as on the fitting rank; whatever needs the factor (fp64 variance, LML, refit) does not exist here."""
+        torch = _torch()
+        self = cls.__new__(cls)
+        self.be = backend or get_backend()
+        self.N, self.D, self.P, self.Np = int(meta["N"]), int(meta["D"]), int(meta["P"]), int(meta["Np"])
+        self.X = tensors["X"]
+        self._Xh = self.X.cpu().numpy()
+        self._xc = self._Xh.mean(axis=0)
+        self._r2 = {}
+        self.Yn = None
+        self.K = self.winv = None
+        self.alpha = tensors["alpha"]
+        self.factored = True
+        self.ls = np.ascontiguousarray(meta["ls"], dtype=np.float64)
+        self.sf2 = float(meta["sf2"])
+        self._f32 = None
+        self._Winv = {"split2": (tensors["W2"], tensors["w_scales"])}
+        self._host_args = None
+        self._amp = None
+        self._Kinv = None
+        self.replica = True
+        return self
 
     # ---- fp32 serving gates -------------------------------------------------------------------------------------
     # The fp32 predict path is stated as: mean within 1e-4, std within 1e-3 (relative to the largest value) of the
@@ -569,118 +614,25 @@ class DeviceGP:
         lsp = self.ls.ctypes.data_as(_lib._dp)
         with be.lock:
             be.bind_stream()
-            for m0 in range(0, M, panel):
-                m1 = min(M, m0 + panel)
-                if method == "inverse_split":
-                    be.check(be.lib.gpk_predict_var_inv_split(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W3),
-                                                              self.Np, _p(q[m0:m1]), m1 - m0, float(kss), float(floor),
-                                                              _p(work), _p(work3), _p(var)))
-                elif method == "inverse_split2":
-                    be.check(be.lib.gpk_predict_var_inv_split2(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W2),
-                                                               _p(w_scales), self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
-                                                               float(floor), _p(work3), _p(var)))
-                elif method == "inverse":
-                    be.check(be.lib.gpk_predict_var_inv(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Wd),
-                                                        self.Np, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
-                                                        float(floor), _p(work), _p(var)))
-                else:
-                    be.check(be.lib.gpk_predict_var(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Ld),
-                                                    self.Np, self.Np, _p(wd), _p(q[m0:m1]), m1 - m0, float(kss),
-                                                    float(floor), _p(work), _p(var)))
-                out[m0:m1].copy_(var[: m1 - m0])
-        return out
-
-    # ---- gated serving: the one place every fp32 surface (estimator, sharded predictor, package GP, per-axis models) goes
-    # through -------------------------------------------------------------------------------------------------------------
-    def _fp64_var_method(self):
-        return "inverse" if ("f64" in self._Winv or self.Np <= self.INVERSE_EAGER_NP) else "solve"
-
-    def _gate_mean(self, dtype, var_method, gated):
-        """(predict dtype, variance method) after the mean gate: an fp32 request for a model whose fp32 mean would leave
-        the stated 1e-4 is served by the fp64 kernels."""
-        torch = _torch()
-        f32 = dtype in ("float32", np.float32, torch.float32)
-        if f32 and gated and not self.fp32_mean_ok():
-            return "float64", ("auto" if var_method in ("inverse_split", "inverse_split2") else var_method)
-        return ("float32" if f32 else "float64"), var_method
-
-    def predict_gated_dev(self, Xq, y_mean, y_std, kss=None, floor=0.0, dtype="float64", var_method="auto", gated=True):
-        """K4 (+ K5 when `kss` is given) with the fp32 serving gates applied: (mean (M, P) tensor of the dtype it was
-        computed in, var (M,) float64 tensor in normalised-target units, or None).  dtype "float32" is a REQUEST: the mean gate (`fp32_mean_ok`) may
-        route the model to the fp64 kernels, and single queries whose fp32 variance is below FP32_VAR_RECHECK_FRACTION of
-        the prior's are recomputed by the fp64 launch.  gated=False: the raw fp32 kernels (tests, A/B timings)."""
-        torch = _torch()
-        pd, vm = self._gate_mean(dtype, var_method, gated)
-        q = self._as_queries(Xq, torch.float32 if pd == "float32" else torch.float64)
-        mean = self.predict_mean_dev(q, y_mean, y_std, pd)
-        if kss is None:
-            return mean, None
-        var = self.predict_var_dev(q, kss, floor, pd, vm)
-        if gated and pd == "float32" and q.shape[0]:
-            low = torch.nonzero(var < self.FP32_VAR_RECHECK_FRACTION * kss).ravel()
-            if low.numel():
-                q64 = (q[low].double() if isinstance(Xq, torch.Tensor)
-                       else self.be.upload(np.ascontiguousarray(Xq, dtype=np.float64)[low.cpu().numpy()]))
-                var[low] = self.predict_var_dev(q64.contiguous(), kss, floor, "float64", self._fp64_var_method())
-        return mean, var
-
-    def predict_packed_dev(self, Xq, y_mean, y_std, kss, floor=0.0, dtype="float32", var_method="auto", gated=True):
-        """One serving step, the whole result in one (M, 2P) float64 device tensor: row m = [mean_m | var_m y_std^2]
-        (un-normalised: what the all-gather of a sharded batch moves).  The fp32 default is ONE C call per panel
-        (gpk_predict_mean_var_split2: K4, K* in split form, the variance launch, a finalising kernel that un-normalises,
-        packs and counts the rows the variance gate must recompute); no torch arithmetic runs unless that count is
-        non-zero.  Other dtypes / methods: the separate launches and gpk_pack_mean_var."""
-        torch = _torch()
-        pd, vm = self._gate_mean(dtype, var_method, gated)
-        f32 = pd == "float32"
-        if vm == "auto":
-            vm = "inverse_split2" if f32 else "inverse"
-        q = self._as_queries(Xq, torch.float32 if f32 else torch.float64)
-        M = q.shape[0]
-        out = self.be.empty((M, 2 * self.P), torch.float64)
-        if M == 0:
-            return out
-        ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
-        ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
-        be = self.be
-        if not (f32 and vm == "inverse_split2"):
-            mean = self.predict_mean_dev(q, ym, ys, pd)
-            var = self.predict_var_dev(q, kss, floor, pd, vm)
-            if gated and f32:
-                low = torch.nonzero(var < self.FP32_VAR_RECHECK_FRACTION * kss).ravel()
-                if low.numel():
-                    var[low] = self.predict_var_dev(q[low].double().contiguous(), kss, floor, "float64", self._fp64_var_method())
-            with be.lock:
-                be.bind_stream()
-                be.check(be.lib.gpk_pack_mean_var(be.h, GPK_F32 if f32 else GPK_F64, _p(mean), _p(var), M, self.P,
-                                                  ys.ctypes.data_as(_lib._dp), _p(out)))
-            return out
-        c = self._f32_data()
-        W2, w_scales = self.split2_inverse_factor()
-        center = self._xc.ctypes.data_as(_lib._dp) if self.mean_kernel_choice() == "mfma" else None
-        panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * 4)) // 128 * 128))
-        panel = min(panel, padded(M))
-        work2 = be.empty((self.Np * panel * 4,), torch.uint8)
-        mean_tmp = be.empty((panel * self.P,), torch.float32)
-        thr = self.FP32_VAR_RECHECK_FRACTION * kss if gated else 0.0
-        nlow = 0
-        with be.lock:
-            be.bind_stream()
-            for m0 in range(0, M, panel):
-                m1 = min(M, m0 + panel)
-                be.check(be.lib.gpk_predict_mean_var_split2(
-                    be.h, _p(c["X"]), _p(c["alpha"]), self.N, self.D, self.P, self.ls.ctypes.data_as(_lib._dp), self.sf2,
-                    center, ym.ctypes.data_as(_lib._dp), ys.ctypes.data_as(_lib._dp), _p(W2), _p(w_scales), self.Np,
-                    _p(q[m0:m1]), m1 - m0, float(kss), float(floor), _p(work2), _p(mean_tmp), float(thr),
-                    _p(be.low_count) if gated else None, _p(out[m0:m1])))
-            if gated:                            # (a 4-byte read-back; rows to recompute are rare: near training points only)
-                seen = int(be.low_count.item()) & 0xFFFFFFFF
-                nlow = (seen - be.low_seen) & 0xFFFFFFFF
-                be.low_seen = seen
-        if nlow:
+            try:
+                for m0 in range(0, M, panel):
+                    m1 = min(M, m0 + panel)
+                    be.check(be.lib.gpk_predict_mean_var_split2(
+                        be.h, _p(c["X"]), _p(c["alpha"]), self.N, self.D, self.P, self.ls.ctypes.data_as(_lib._dp), self.sf2,
+                        center, ym.ctypes.data_as(_lib._dp), ys.ctypes.data_as(_lib._dp), _p(W2), _p(w_scales), self.Np,
+                        _p(q[m0:m1]), m1 - m0, float(kss), float(floor), _p(work2), _p(mean_tmp), float(thr),
+                        _p(be.low_count) if gated else None, _p(out[m0:m1])))
+            finally:
+                if gated:                        # (a 4-byte read-back on every exit path: the running counter and its host
+                    seen = int(be.low_count.item()) & 0xFFFFFFFF     #  mirror stay in step even when a panel failed)
+                    nlow = (seen - be.low_seen) & 0xFFFFFFFF
+                    be.low_seen = seen
+        if nlow and not self.replica:           # (a replica leaves them to ShardedPredictor: the fitting rank recomputes them)
             ys2 = torch.as_tensor(ys ** 2, device=be.device)
-            low = torch.nonzero(out[:, self.P] < thr * float(ys[0] ** 2)).ravel()
-            v64 = self.predict_var_dev(q[low].double().contiguous(), kss, floor, "float64", self._fp64_var_method())
+            # the kernel counted v < thr before un-normalising; re-select on the packed value with a hair of slack so that a
+            # boundary row is never counted and then missed (recomputing one row too many is harmless)
+            low = torch.nonzero(out[:, self.P] <= thr * float(ys[0] ** 2) * (1.0 + 1e-12)).ravel()
+            v64 = self.predict_var_dev(self._rows64(Xq, q, low), kss, floor, "float64", self._fp64_var_method())
             out[low, self.P:] = v64[:, None] * ys2[None, :]
         return out
 

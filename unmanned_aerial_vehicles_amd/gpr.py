@@ -241,7 +241,7 @@ class GaussianProcessRegressor:
         mean_d, var_d = dev.predict_gated_dev(X, self._y_train_mean, self._y_train_std, kss, 0.0, self.predict_dtype,
                                               self.var_method, gated)   # variance clipped at 0 (_gpr.py:479-485)
         if not return_std:
-            mean = mean_d.cpu().numpy()
+            mean = mean_d.double().cpu().numpy()       # float64 whatever dtype served it, as scikit-learn returns
             return mean[:, 0] if mean.shape[1] == 1 else mean
         both = torch.cat([mean_d.double(), var_d[:, None]], dim=1).cpu().numpy()     # one device->host copy
         mean, var = both[:, :-1], both[:, -1]
