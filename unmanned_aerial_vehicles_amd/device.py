@@ -614,6 +614,111 @@ class DeviceGP:
         lsp = self.ls.ctypes.data_as(_lib._dp)
         with be.lock:
             be.bind_stream()
+            for m0 in range(0, M, panel):
+                m1 = min(M, m0 + panel)
+                if method == "inverse_split":
+                    be.check(be.lib.gpk_predict_var_inv_split(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W3),
+                                                              self.Np, _p(q[m0:m1]), m1 - m0, float(kss), float(floor),
+                                                              _p(work), _p(work3), _p(var)))
+                elif method == "inverse_split2":
+                    be.check(be.lib.gpk_predict_var_inv_split2(be.h, _p(Xd), self.N, self.D, lsp, self.sf2, _p(W2),
+                                                               _p(w_scales), self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
+                                                               float(floor), _p(work3), _p(var)))
+                elif method == "inverse":
+                    be.check(be.lib.gpk_predict_var_inv(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Wd),
+                                                        self.Np, self.Np, _p(q[m0:m1]), m1 - m0, float(kss),
+                                                        float(floor), _p(work), _p(var)))
+                else:
+                    be.check(be.lib.gpk_predict_var(be.h, code, _p(Xd), self.N, self.D, lsp, self.sf2, _p(Ld),
+                                                    self.Np, self.Np, _p(wd), _p(q[m0:m1]), m1 - m0, float(kss),
+                                                    float(floor), _p(work), _p(var)))
+                out[m0:m1].copy_(var[: m1 - m0])
+        return out
+
+    # ---- gated serving: the one place every fp32 surface (estimator, sharded predictor, package GP, per-axis models) goes
+    # through -------------------------------------------------------------------------------------------------------------
+    def _rows64(self, Xq, q, rows):
+        """The caller's own rows `rows` of a query batch as a contiguous float64 device tensor (NOT the fp32-rounded copy
+        the fp32 kernels were given: an fp64 re-check sees the queries the caller passed)."""
+        torch = _torch()
+        if isinstance(Xq, torch.Tensor):
+            return Xq[rows.to(Xq.device)].to(device=self.be.device, dtype=torch.float64).contiguous()
+        return self.be.upload(np.ascontiguousarray(np.asarray(Xq, dtype=np.float64)[rows.cpu().numpy()]))
+
+    def _fp64_var_method(self):
+        if self.replica:
+            raise RuntimeError("a serving replica holds no factor: fp64 variances are computed on the rank that fitted the model")
+        return "inverse" if ("f64" in self._Winv or self.Np <= self.INVERSE_EAGER_NP) else "solve"
+
+    def _gate_mean(self, dtype, var_method, gated):
+        """(predict dtype, variance method) after the mean gate: an fp32 request for a model whose fp32 mean would leave
+        the stated 1e-4 is served by the fp64 kernels."""
+        torch = _torch()
+        f32 = dtype in ("float32", np.float32, torch.float32)
+        if f32 and gated and not self.fp32_mean_ok():
+            return "float64", ("auto" if var_method in ("inverse_split", "inverse_split2") else var_method)
+        return ("float32" if f32 else "float64"), var_method
+
+    def predict_gated_dev(self, Xq, y_mean, y_std, kss=None, floor=0.0, dtype="float64", var_method="auto", gated=True):
+        """K4 (+ K5 when `kss` is given) with the fp32 serving gates applied: (mean (M, P) tensor of the dtype it was
+        computed in, var (M,) float64 tensor in normalised-target units, or None).  dtype "float32" is a REQUEST: the mean gate (`fp32_mean_ok`) may
+        route the model to the fp64 kernels, and single queries whose fp32 variance is below FP32_VAR_RECHECK_FRACTION of
+        the prior's are recomputed by the fp64 launch.  gated=False: the raw fp32 kernels (tests, A/B timings)."""
+        torch = _torch()
+        pd, vm = self._gate_mean(dtype, var_method, gated)
+        q = self._as_queries(Xq, torch.float32 if pd == "float32" else torch.float64)
+        mean = self.predict_mean_dev(q, y_mean, y_std, pd)
+        if kss is None:
+            return mean, None
+        var = self.predict_var_dev(q, kss, floor, pd, vm)
+        if gated and pd == "float32" and q.shape[0]:
+            low = torch.nonzero(var < self.FP32_VAR_RECHECK_FRACTION * kss).ravel()
+            if low.numel():
+                var[low] = self.predict_var_dev(self._rows64(Xq, q, low), kss, floor, "float64", self._fp64_var_method())
+        return mean, var
+
+    def predict_packed_dev(self, Xq, y_mean, y_std, kss, floor=0.0, dtype="float32", var_method="auto", gated=True):
+        """One serving step, the whole result in one (M, 2P) float64 device tensor: row m = [mean_m | var_m y_std^2]
+        (un-normalised: what the all-gather of a sharded batch moves).  The fp32 default is ONE C call per panel
+        (gpk_predict_mean_var_split2: K4, K* in split form, the variance launch, a finalising kernel that un-normalises,
+        packs and counts the rows the variance gate must recompute); no torch arithmetic runs unless that count is
+        non-zero.  Other dtypes / methods: the separate launches and gpk_pack_mean_var."""
+        torch = _torch()
+        pd, vm = self._gate_mean(dtype, var_method, gated)
+        f32 = pd == "float32"
+        if vm == "auto":
+            vm = "inverse_split2" if f32 else "inverse"
+        q = self._as_queries(Xq, torch.float32 if f32 else torch.float64)
+        M = q.shape[0]
+        out = self.be.empty((M, 2 * self.P), torch.float64)
+        if M == 0:
+            return out
+        ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_mean, dtype=np.float64), (self.P,)))
+        ys = np.ascontiguousarray(np.broadcast_to(np.asarray(y_std, dtype=np.float64), (self.P,)))
+        be = self.be
+        if not (f32 and vm == "inverse_split2"):
+            mean = self.predict_mean_dev(q, ym, ys, pd)
+            var = self.predict_var_dev(q, kss, floor, pd, vm)
+            if gated and f32:
+                low = torch.nonzero(var < self.FP32_VAR_RECHECK_FRACTION * kss).ravel()
+                if low.numel():
+                    var[low] = self.predict_var_dev(self._rows64(Xq, q, low), kss, floor, "float64", self._fp64_var_method())
+            with be.lock:
+                be.bind_stream()
+                be.check(be.lib.gpk_pack_mean_var(be.h, GPK_F32 if f32 else GPK_F64, _p(mean), _p(var), M, self.P,
+                                                  ys.ctypes.data_as(_lib._dp), _p(out)))
+            return out
+        c = self._f32_data()
+        W2, w_scales = self.split2_inverse_factor()
+        center = self._xc.ctypes.data_as(_lib._dp) if self.mean_kernel_choice() == "mfma" else None
+        panel = max(128, min(self.VAR_PANEL_MAX, (self.VAR_PANEL_BYTES // (self.Np * 4)) // 128 * 128))
+        panel = min(panel, padded(M))
+        work2 = be.empty((self.Np * panel * 4,), torch.uint8)
+        mean_tmp = be.empty((panel * self.P,), torch.float32)
+        thr = self.FP32_VAR_RECHECK_FRACTION * kss if gated else 0.0
+        nlow = 0
+        with be.lock:
+            be.bind_stream()
             try:
                 for m0 in range(0, M, panel):
                     m1 = min(M, m0 + panel)
