@@ -600,8 +600,13 @@ def main():
         if use_w:
             # the inverse factor (34 GB) and its scratch come from torch's caching allocator: map them once outside the
             # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
-            warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64),
-                    be.empty((dev.Np, dev.Np), torch.float32), be.empty((dev.Np * dev.Np * 4,), torch.uint8)]
+            # (the fp16 x 2 operand is split straight from the fp64 inverse factor: no fp32 copy exists on that route;
+            # the trtri scratch is gone again before the split operand is allocated, as in DeviceGP)
+            warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64)]
+            if method != "inverse_split2":
+                warm.append(be.empty((dev.Np, dev.Np), torch.float32))
+            del warm
+            warm = be.empty((dev.Np * dev.Np * 4,), torch.uint8)
             del warm
             torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -21,8 +21,9 @@ def main():
     p = lambda t: C.c_void_p(t.data_ptr())
     X = torch.as_tensor(np.random.default_rng(0).standard_normal((n, 9)), device=be.device)
     ls = np.full(9, 2.0)
-    K0 = be.empty((n, n), torch.float64)
-    be.check(be.lib.gpk_gram(be.h, _lib.GPK_F64, p(X), n, 9, ls.ctypes.data_as(_lib._dp), 1.0, 0.1001, p(K0), n))
+    ld = n + int(os.environ.get('PAD', '0'))
+    K0 = be.empty((n, ld), torch.float64)
+    be.check(be.lib.gpk_gram(be.h, _lib.GPK_F64, p(X), n, 9, ls.ctypes.data_as(_lib._dp), 1.0, 0.1001, p(K0), ld))
     winv = be.empty((n, 128), torch.float64)
     info = C.c_int(0)
     for it in range(3):
@@ -30,9 +31,10 @@ def main():
         torch.cuda.synchronize()
         if it == 2:
             os.environ["GPK_PTILE_TRACE"] = path
-        be.check(be.lib.gpk_potrf(be.h, p(K), n, n, p(winv), C.byref(info)))
+        be.check(be.lib.gpk_potrf(be.h, p(K), n, ld, p(winv), C.byref(info)))
     os.environ.pop("GPK_PTILE_TRACE", None)
     t = np.loadtxt(path)
+    t = t[:-4]
     nt = n // 128
     t0 = t[:, 0].min()
     us = lambda v: (v - t0) / 100.0
@@ -43,7 +45,9 @@ def main():
             r = t[idx]
             if i == j:
                 ph = " ".join(f"{us(r[2 + b]):7.1f}" for b in range(8))
-                print(f"D({j:2d})     start {us(r[0]):7.1f} kloop {us(r[1]):7.1f} | phaseA ends {ph} | done {us(r[10]):7.1f}")
+                clk = (r[15] - r[14]) / max(r[10] - r[0], 1) * 100.0
+                print(f"      shader clock over the task: {clk:.0f} MHz")
+                print(f"D({j:2d})     start {us(r[0]):7.1f} lastcol-seen {us(r[11]):7.1f} kt-8 {us(r[12]):7.1f} kt-4 {us(r[13]):7.1f} kloop {us(r[1]):7.1f} | phaseA ends {ph} | done {us(r[10]):7.1f}")
             elif i <= j + 2 or i == nt - 1:
                 print(f"T({i:2d},{j:2d})  start {us(r[0]):7.1f} kloop {us(r[1]):7.1f} Wready {us(r[2]):7.1f} Wlds {us(r[3]):7.1f} "
                       f"apply {us(r[4]):7.1f} done {us(r[5]):7.1f}")

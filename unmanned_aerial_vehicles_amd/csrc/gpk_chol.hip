@@ -587,6 +587,13 @@ int trsm_right_rec(gpk_handle h, double* B, int64_t ldb, int64_t m, const double
 }
 
 int potrf_rec(gpk_handle h, double* A, int64_t lda, int64_t n, double* winv, int64_t row0) {
+  if (n <= h->ptile_max_np && n >= 4 * NB) {
+    // the bottom of the recursion: one persistent launch per diagonal block of this size (gpk_ptile.hip) instead of its
+    // ~3 n / 128 dependent launches
+    int used = 0;
+    GPK_TRY(gpk_potrf_ptile(h, A, n, lda, winv, (int)row0, &used));
+    if (used) return GPK_OK;
+  }
   if (n == NB) {
     hipLaunchKernelGGL(leaf_kernel<true>, dim3(h->batch), dim3(256), 0, h->stream, A, (long long)lda, (int)row0,
                        h->d_info, winv, gpk_bstride(h, A), gpk_bstride(h, winv));
@@ -703,12 +710,12 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, doubl
   GPK_REQUIRE(h, ((uintptr_t)A % 16) == 0 && ((uintptr_t)winv % 16) == 0, "potrf: A, winv must be 16-byte aligned");
   const int nb = h->batch;                         // batched mode: info receives one entry per problem
   GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, nb * sizeof(int), h->stream));
-  int one_launch = 0;
   gpk_time_begin(h, GPK_TIMED_POTRF);
-  int rc = gpk_potrf_ptile(h, A, Np, lda, winv, 0, &one_launch);
-  if (rc == GPK_OK && !one_launch) rc = potrf_rec(h, A, lda, Np, winv, 0);
+  h->ptile_launches = 0;
+  const int rc = potrf_rec(h, A, lda, Np, winv, 0);
   gpk_time_end(h);
   GPK_TRY(rc);
+  const int one_launch = h->ptile_launches > 0;
   int hinfo_all[GPK_MAX_BATCH] = {0};
   GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo_all, h->d_info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));

@@ -47,6 +47,7 @@ struct gpk_context {
   int ptile_max_np = 16384;
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
+  int ptile_launches = 0;    // one-launch factorisations issued by the current gpk_potrf (their abort words are checked at its end)
   std::string ptile_trace_path;   // GPK_PTILE_TRACE (debugging aid): where the next launch's time stamps go
   long long ptile_trace_n = 0;
   int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
@@ -99,7 +100,7 @@ struct gpk_context {
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
 
 // ---- one-launch tile Cholesky (gpk_ptile.hip) -----------------------------------------
-constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row counters
+constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row counters; one pause word per CU
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
 int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used);
 int gpk_potrf_ptile_check(gpk_handle h);

@@ -56,6 +56,7 @@ constexpr int OS = 66;                        // row stride (doubles) of the 128
 constexpr int LDS_BYTES = 80 * 1024;          // two workgroups per CU
 constexpr int CTL_OFF = LDS_BYTES - 64;       // a few control words at the end
 constexpr long long GPK_PTILE_TIMEOUT_TICKS = 400000000ll;   // 4 s of s_memrealtime
+constexpr int PAUSE_OFF = 16 + 8 * 512;       // ctrl ints: one word per compute unit (key < 1024)
 
 static_assert(4 * OPB <= CTL_OFF, "staging buffers");
 static_assert(36 * BLK * 8 <= CTL_OFF, "W_jj image");
@@ -67,7 +68,8 @@ struct PTParams {
   double* winv; long long strideW;
   int* info; int row0;
   int nt, batch, ntasks;
-  int* ctrl;                                       // [0] ticket counter, [1] abort; ready counters from ctrl + 16
+  int* ctrl;                                       // [0] ticket counter, [1] abort; ready counters from ctrl + 16;
+                                                   // "a critical diagonal task runs on this CU" words from ctrl + PAUSE_OFF
   long long* trace;                                // GPK_PTILE_TRACE: 16 time stamps per task (100 MHz), or null
 };
 
@@ -99,9 +101,22 @@ __device__ int poll_ready(const int* ra, const int* rb, int need, int* abortp) {
     if (v >= need) return v;
     if ((it & 31) == 31) {
       if (ld_agent(abortp) != 0) return -1;
-      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GPK_PTILE_TIMEOUT_TICKS) { st_agent(abortp, 1); return -1; }
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GPK_PTILE_TIMEOUT_TICKS) { st_agent(abortp, 1); st_agent(abortp + (GPK_PTILE_CTRL_INTS - 1), 1); return -1; }
     }
-    __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// one lane: spin until *p == 0; -1 when the launch is aborted
+__device__ int poll_clear(const int* p, int* abortp) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0;; ++it) {
+    if (ld_agent(p) == 0) return 0;
+    if ((it & 31) == 31) {
+      if (ld_agent(abortp) != 0) return -1;
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GPK_PTILE_TIMEOUT_TICKS) { st_agent(abortp, 1); st_agent(abortp + (GPK_PTILE_CTRL_INTS - 1), 1); return -1; }
+    }
+    __builtin_amdgcn_s_sleep(8);
   }
 }
 
@@ -138,6 +153,12 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int* abortp = p.ctrl + 1;
+  // Which compute unit this workgroup runs on (XCC, shader engine / array, CU): the diagonal task - the critical path -
+  // raises a word for its CU while its last k-step and its factorisation run, and the OTHER workgroup resident on that CU
+  // (two per CU) stands still meanwhile instead of taking half of the CU's matrix pipe and memory queue.
+  const int cu_key = (int)((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u) * 128u +
+                           ((__builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (6 << 11))) & 127u));
+  int* pausep = p.ctrl + PAUSE_OFF + cu_key;
   const int nt = p.nt;
   const long long ntp = (long long)nt * (nt + 1) / 2;
 
@@ -152,6 +173,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     const int task = ctl[0];
     if (task >= p.ntasks) return;
     PT_STAMP(0);
+    if (p.trace && tid == 0) p.trace[(long long)task * 16 + 14] = (long long)__builtin_readcyclecounter();
     // task -> (problem b, tile row i, tile column j); column-major list: column j starts at j nt - j (j - 1) / 2
     const int b = task % p.batch;
     const long long tt = task / p.batch;
@@ -167,260 +189,393 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     const long long lda = p.lda;
     double* Atile = A + (long long)i * TS * lda + (long long)j * TS;
     const bool diag = (i == j);
-    // block row owned by this wave: the diagonal task pairs a long and a short row on every SIMD (waves w, w + 4)
-    const int rw = diag ? (wave < 4 ? wave : 11 - wave) : wave;
+    // One body per task kind, instantiated twice: the two kinds then have their own accumulators.  (As one body with
+    // run-time branches the accumulators of both k-loops meet in phi nodes and the register allocator, at its 128-register
+    // limit, renames and spills them inside the loops.)
+    auto run = [&](auto dc) -> bool {
+      constexpr bool DIAG = decltype(dc)::value;
+      // the diagonal task IS the critical path: its waves go first wherever they share a SIMD with another workgroup's
+      __builtin_amdgcn_s_setprio(DIAG ? 3 : 0);
+      // block row owned by this wave: the diagonal task pairs a long and a short row on every SIMD (waves w, w + 4)
+      const int rw = DIAG ? (wave < 4 ? wave : 11 - wave) : wave;
 
-    // ---- accumulators start from the tile itself (transposed blocks)
-    d4 S[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};
-    {
-      const int t0 = fresh_tid(), lr = t0 & 15, lq = (t0 >> 4) & 3;
-      const double* src = Atile + (long long)(16 * rw + lr) * lda + lq;
-      sfor<0, 8>([&](auto kc) {          // (a diagonal task reads its blocks right of the diagonal too: valid memory,
-        constexpr int KB = decltype(kc)::value;   //  they ride along through the k-loop and are dropped after it)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) S[KB][t] = src[16 * KB + 4 * t];
-      });
-    }
-
-    // ---- k-loop over the finished tile columns 0 .. j - 1 (8 k-tiles each), register-staged pipeline as in gpk_gemm.hip
-    const int nkt = 8 * j;
-    if (nkt > 0) {
-      const char* pj = reinterpret_cast<const char*>(A + (long long)j * TS * lda);     // row panel j: A operand
-      const char* pi = reinterpret_cast<const char*>(A + (long long)i * TS * lda);     // row panel i: B operand
-      const int tk = fresh_tid(), lr = tk & 15, lq = (tk >> 4) & 3;
-      unsigned voff[2];
+      // ---- accumulators start from the tile itself (transposed blocks)
+      d4 S[8];
+  #pragma unroll
+      for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};
       {
-        const int c = tk & 7, rr = tk >> 3;
-        voff[0] = (unsigned)(((long long)rr * lda + c * 2) * 8);
-        voff[1] = (unsigned)(((long long)(rr + 64) * lda + c * 2) * 8);
+        const int t0 = fresh_tid(), lr = t0 & 15, lq = (t0 >> 4) & 3;
+        const double* src = Atile + (long long)(16 * rw + lr) * lda + lq;
+        sfor<0, 8>([&](auto kc) {          // (a diagonal task reads its blocks right of the diagonal too: valid memory,
+          constexpr int KB = decltype(kc)::value;   //  they ride along through the k-loop and are dropped after it)
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) S[KB][t] = src[16 * KB + 4 * t];
+        });
       }
-      int avail = 0;                                   // tile columns known to be final in rows i and j
-      auto need_cols = [&](int need) -> bool {        // uniform; false = aborted
-        if (avail >= need) return true;
-        if (tid == 0) ctl[1] = poll_ready(ready + i, diag ? nullptr : ready + j, need, abortp);
+
+      // ---- k-loop over the finished tile columns 0 .. j - 1 (8 k-tiles each), register-staged pipeline as in gpk_gemm.hip
+      const int nkt = 8 * j;
+      if (nkt > 0) {
+        const char* pj = reinterpret_cast<const char*>(A + (long long)j * TS * lda);     // row panel j: A operand
+        const char* pi = reinterpret_cast<const char*>(A + (long long)i * TS * lda);     // row panel i: B operand
+        int avail = 0;                                   // tile columns known to be final in rows i and j
+        auto need_cols = [&](int need) -> bool {        // uniform; false = aborted
+          if (avail >= need) return true;
+          if (tid == 0) ctl[1] = poll_ready(ready + i, DIAG ? nullptr : ready + j, need, abortp);
+          __syncthreads();
+          const int v = ctl[1];
+          __syncthreads();
+          if (v < 0) return false;
+          avail = min(v, j);
+          if (avail >= j) PT_STAMP(11);
+
+          return true;
+        };
+        if constexpr (DIAG) {
+          // ---- the diagonal task's k-loop: both operands are rows of panel j, and its last k-step - the tile the
+          // sub-diagonal task has just published, 2-3 us away in memory - is on the critical path of the whole
+          // factorisation.  One operand image per k-tile, brought in by LDS-DMA (buffer_load ... lds: no staging registers)
+          // into a ring of FOUR 16 KiB stages: three k-tiles are in flight while one is multiplied, so a k-step of 8 k-tiles
+          // costs about one memory latency instead of eight.  Unpadded 128-byte rows, the 16-byte chunks of a row XOR-swizzled
+          // by s(r) = (r & 7) ^ (r >> 3), r = row & 15: conflict-free ds_read_b128 fragments.  A wave instruction fills 1 KiB
+          // = 8 rows; the compiler knows nothing of these writes: the counted s_waitcnt + s_barrier below are the ordering.
+          const int td = fresh_tid(), lane = td & 63, lr = td & 15, lq = (td >> 4) & 3;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pj), 0, 0x7fffffff, 0x00020000);
+          unsigned dvo[2];
+  #pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int P = (2 * wave + u) * 64 + lane, row = P >> 3, r = row & 15;
+            const int c = (P & 7) ^ ((r & 7) ^ (r >> 3));
+            dvo[u] = (unsigned)(((long long)row * lda + 2 * c) * 8);
+          }
+          auto issue = [&](int kt) {
+            char* st = lds + (kt & 3) * 16384 + 2 * wave * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)st, 16, dvo[0], kt * (BK * 8), 0, 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st + 1024), 16, dvo[1], kt * (BK * 8), 0, 16);
+          };
+          const int frag = lr * 128, sw = (lr & 7) ^ (lr >> 3);
+          const int off0 = frag + (((2 * lq) ^ sw) << 4), off1 = frag + (((2 * lq + 1) ^ sw) << 4);
+          // The accumulators' initial values (plain loads issued at the start of the task) are claimed HERE: left to the
+          // compiler, the wait for them lands in front of the first MFMA inside the loop - as s_waitcnt vmcnt(0), executed
+          // on every trip, which would also wait for the k-tiles in flight.
+          asm volatile("" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6]), "+v"(S[7]));
+          // `issued` k-tiles have been put in flight so far.  The loop never WAITS for a tile column while it still has
+          // landed k-tiles to multiply: when the next column is not final yet it works off what it has (so that nothing
+          // stale is left for the moment the fresh column arrives) and blocks only with its ring empty - then three k-tiles
+          // go out at once, the fourth behind the next barrier.
+          int issued = 0;
+#pragma unroll 1
+          for (int kt = 0; kt < nkt; ++kt) {
+            if (issued == kt) {                    // ring empty: the column of k-tile kt must be final before anything moves
+              // waiting for the LAST column: from here to the end of the task this workgroup is the critical path
+              if ((kt >> 3) == j - 1 && avail < j && tid == 0) st_agent(pausep, j + 1);
+              if (!need_cols((kt >> 3) + 1)) return false;
+              // (stages kt .. kt + 2 are free: their last readers passed the barrier of iteration kt - 1)
+              while (issued < nkt && issued < kt + 3 && (issued >> 3) < avail) issue(issued++);
+            }
+            // k-tile kt has landed once at most the DMAs of the k-tiles issued after it are outstanding (two per k-tile)
+            const int later = issued - 1 - kt;
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave's share is in; stage (kt + 3) & 3 = (kt - 1) & 3 has been read
+            if (kt == nkt - 8) PT_STAMP(12);
+            if (kt == nkt - 4) PT_STAMP(13);
+            while (issued < nkt && issued < kt + 4 && (issued >> 3) < avail) issue(issued++);
+            const char* la = lds + (kt & 3) * 16384;
+            // only the blocks on and left of the diagonal are part of the task: block row rw multiplies blocks 0 .. rw
+            // (waves w and w + 4 share a SIMD and own rows w and 7 - w: nine blocks per SIMD instead of sixteen).  Every
+            // fragment is read (LDS reads are cheap), the MFMAs of the other blocks are branched over (wave-uniform).
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int off = hh == 0 ? off0 : off1;
+              dv2 bf = *reinterpret_cast<const dv2*>(la + rw * 2048 + off);
+              dv2 af[8];
+#pragma unroll
+              for (int x = 0; x < 8; ++x) af[x] = *reinterpret_cast<const dv2*>(la + x * 2048 + off);
+              bf.x = -bf.x; bf.y = -bf.y;
+              sfor<0, 8>([&](auto xc) {
+                constexpr int KB = decltype(xc)::value;
+                if (KB <= rw) {
+                  S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB].x, bf.x, S[KB], 0, 0, 0);
+                  S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB].y, bf.y, S[KB], 0, 0, 0);
+                }
+              });
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();            // the last stage has been read (no DMA is outstanding: vmcnt(0) above)
+        } else {
+        const int tk = fresh_tid(), lr = tk & 15, lq = (tk >> 4) & 3;
+        unsigned voff[2];
+        {
+          const int c = tk & 7, rr = tk >> 3;
+          voff[0] = (unsigned)(((long long)rr * lda + c * 2) * 8);
+          voff[1] = (unsigned)(((long long)(rr + 64) * lda + c * 2) * 8);
+        }
+        if (!need_cols(1)) return false;
+        int pause_seen = 0;
+        V16 ra[2], rb[2];
+        load_ktile(pj, voff, ra);
+        load_ktile(pi, voff, rb);
+        store_ktile(lds, tk, ra);
+        store_ktile(lds + OPB, tk, rb);
+        {
+          const int k1 = min(1, nkt - 1);
+          load_ktile(pj + k1 * (BK * 8), voff, ra);
+          load_ktile(pi + k1 * (BK * 8), voff, rb);
+        }
         __syncthreads();
-        const int v = ctl[1];
+        for (int kt = 0; kt < nkt; ++kt) {
+          const int cur = kt & 1;
+          store_ktile(lds + (cur ^ 1) * 2 * OPB, tk, ra);
+          store_ktile(lds + (cur ^ 1) * 2 * OPB + OPB, tk, rb);
+          const int kn = min(kt + 2, nkt - 1);
+          if (!need_cols((kn >> 3) + 1)) return false;
+          if (tid == 0) {                                   // the CU's pause word, read one iteration ahead of its use
+            ctl[2 + cur] = pause_seen;
+            pause_seen = ld_agent(pausep);
+          }
+          load_ktile(pj + (long long)kn * (BK * 8), voff, ra);
+          load_ktile(pi + (long long)kn * (BK * 8), voff, rb);
+          const char* la = lds + cur * 2 * OPB;                     // rows of panel j
+          const char* lb = la + OPB;                                // rows of panel i (the same rows in a diagonal task)
+  #pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            dv2 bf = *reinterpret_cast<const dv2*>(lb + (16 * rw + lr) * ROWB + (4 * lq + 2 * hh) * 8);
+            bf.x = -bf.x; bf.y = -bf.y;
+            sfor<0, 2>([&](auto gc) {
+              constexpr int G = decltype(gc)::value;
+              dv2 af[4];
+  #pragma unroll
+              for (int x = 0; x < 4; ++x)
+                af[x] = *reinterpret_cast<const dv2*>(la + (16 * (4 * G + x) + lr) * ROWB + (4 * lq + 2 * hh) * 8);
+              sfor<0, 4>([&](auto xc) {
+                constexpr int KB = 4 * G + decltype(xc)::value;
+                S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].x, bf.x, S[KB], 0, 0, 0);
+                S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].y, bf.y, S[KB], 0, 0, 0);
+              });
+            });
+          }
+          __syncthreads();
+          // A critical task (the diagonal task of column c, or the tile below it) runs on this CU and has raised c + 1: stand
+          // still - but only a task of column >= c does, which nothing on the critical task's dependency chain waits for.
+          if (ctl[2 + cur] != 0 && j >= ctl[2 + cur] - 1 && i != j + 1) {
+            if (tid == 0) ctl[1] = poll_clear(pausep, abortp);
+            __syncthreads();
+            if (ctl[1] < 0) return false;
+            pause_seen = 0;
+            __syncthreads();
+          }
+        }
+        }
+      }
+
+      PT_STAMP(1);
+      if constexpr (!DIAG) {
+        // =================================================== off-diagonal task: X^T = W_jj X^^T, in place, then publish
+        if (tid == 0) {
+          if (i == j + 1) st_agent(pausep, j + 1);          // the tile below the diagonal: critical from here to its publication
+          ctl[1] = poll_ready(ready + j, nullptr, j + 1, abortp);
+        }
         __syncthreads();
-        if (v < 0) return false;
-        avail = min(v, j);
+        if (ctl[1] < 0) return false;
+        PT_STAMP(2);
+        const int ta = fresh_tid(), lr = ta & 15, lq = (ta >> 4) & 3;
+        double* wl = reinterpret_cast<double*>(lds);
+        {
+          // the 36 lower blocks of W_jj (128 x 128 row-major) -> block-major LDS image, block (mb, kb) at mb (mb + 1) / 2 + kb
+          const double* wj = Wv + (long long)j * TS * TS;
+          const __amdgpu_buffer_rsrc_t rs =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(wj), 0, 0x7fffffff, 0x00020000);
+          V16 v[9];                                                 // all nine 16-byte pieces of a thread in flight at once
+  #pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            const int e = ta + NT * u, blk = e >> 7, rowb = (e & 127) >> 3, cp = e & 7;
+            int mb = 0;
+            while ((mb + 1) * (mb + 2) / 2 <= blk) ++mb;
+            const int kb = blk - mb * (mb + 1) / 2;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((16 * mb + rowb) * TS + 16 * kb + 2 * cp) * 8), 0, 16);
+          }
+  #pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            const int e = ta + NT * u, blk = e >> 7, rowb = (e & 127) >> 3, cp = e & 7;
+            const dv2 d = __builtin_bit_cast(dv2, v[u]);
+            wl[blk * BLK + rowb * BS + 2 * cp] = d.x;
+            wl[blk * BLK + rowb * BS + 2 * cp + 1] = d.y;
+          }
+        }
+        __syncthreads();
+        PT_STAMP(3);
+        // the 36 block products in the order (MB descending - block MB needs the OLD blocks 0 .. MB only -, KB ascending),
+        // the four A values of the next product read from LDS while the current one's MFMAs run
+        {
+          double an[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) an[t] = wl[(7 * 8 / 2) * BLK + lr * BS + lq + 4 * t];        // (MB, KB) = (7, 0)
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+          sfor<0, 36>([&](auto pc) {
+            constexpr int PI = decltype(pc)::value;
+            constexpr int MB = PI < 8 ? 7 : PI < 15 ? 6 : PI < 21 ? 5 : PI < 26 ? 4 : PI < 30 ? 3 : PI < 33 ? 2 : PI < 35 ? 1 : 0;
+            constexpr int KB = PI - (36 - (MB + 1) * (MB + 2) / 2);
+            double ac[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ac[t] = an[t];
+            if constexpr (PI < 35) {
+              constexpr int MN = KB == MB ? MB - 1 : MB, KN = KB == MB ? 0 : KB + 1;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) an[t] = wl[(MN * (MN + 1) / 2 + KN) * BLK + lr * BS + lq + 4 * t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], S[KB][t], acc, 0, 0, 0);
+            if constexpr (KB == MB) {
+              S[MB] = acc;
+              acc = d4{0.0, 0.0, 0.0, 0.0};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        PT_STAMP(4);
+        __syncthreads();                                            // every wave is done with the W image
+        // S[mb][t] (lane n = lr, q = lq) = L_ij[16 w + n][16 mb + q + 4 t]: through LDS in two column halves, then
+        // whole 512-byte row pieces with 16-byte sc1 stores
+        double* ob = reinterpret_cast<double*>(lds);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(Atile, 0, 0x7fffffff, 0x00020000);
+        sfor<0, 2>([&](auto hc) {
+          constexpr int hf = decltype(hc)::value;
+          sfor<0, 4>([&](auto mc) {
+            constexpr int ML = decltype(mc)::value;
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) ob[(16 * wave + lr) * OS + 16 * ML + lq + 4 * t] = S[ML + 4 * hf][t];
+          });
+          __syncthreads();
+  #pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = ta + NT * u, row = e >> 5, c2 = e & 31;
+            const V16 v = *reinterpret_cast<const V16*>(ob + row * OS + 2 * c2);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, (unsigned)(((long long)row * lda + 64 * hf + 2 * c2) * 8), 0, 16);
+          }
+          __syncthreads();
+        });
+        wait_vm0();
+        __syncthreads();
+        if (tid == 0) {
+          st_agent(ready + i, j + 1);
+          if (i == j + 1) st_agent(pausep, 0);
+        }
+        PT_STAMP(5);
         return true;
-      };
-      if (!need_cols(1)) return;
-      V16 ra[2], rb[2];
-      load_ktile(pj, voff, ra);
-      load_ktile(pi, voff, rb);
-      store_ktile(lds, tk, ra);
-      store_ktile(lds + OPB, tk, rb);
-      {
-        const int k1 = min(1, nkt - 1);
-        load_ktile(pj + k1 * (BK * 8), voff, ra);
-        load_ktile(pi + k1 * (BK * 8), voff, rb);
+      } else {
+
+      // ======================================================= diagonal task: L_jj and W_jj = L_jj^-1 from the accumulators
+      // Slot S[k] of the wave that owns block row / column rw:  k <= rw: block (rw, k) of the updated tile, transposed,
+      // until block column k is final (then L(rw, k)^T, needed for one more step);  k >= rw: block (k, rw) of the forward
+      // substitution for the inverse (R = -sum L W, then W(k, rw)).  Slot rw changes hands when the wave's own diagonal
+      // block has gone to the factoring wave.
+      const int tl = fresh_tid(), lane = tl & 63, lr = tl & 15, lq = (tl >> 4) & 3;
+      double* dblk = reinterpret_cast<double*>(lds);                // the current diagonal block, row-major
+      double* wd = dblk + BLK;                                      // wd[b][r][c] = W_bb[c][r]
+      double* lcol = wd + 8 * BLK;                                  // two block columns of L: lcol[buf][block row]
+      double* Wj = Wv + (long long)j * TS * TS;
+      int* info = p.info + b;
+      __syncthreads();                                              // the k-loop's last reads of the staging buffers
+      sfor<1, 8>([&](auto kc) {                                     // the blocks right of the diagonal are not part of the task
+        constexpr int KB = decltype(kc)::value;
+        if (KB > rw) S[KB] = d4{0.0, 0.0, 0.0, 0.0};
+      });
+      if (rw == 0) {
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[0][t];
       }
       __syncthreads();
-      for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        store_ktile(lds + (cur ^ 1) * 2 * OPB, tk, ra);
-        store_ktile(lds + (cur ^ 1) * 2 * OPB + OPB, tk, rb);
-        const int kn = min(kt + 2, nkt - 1);
-        if (!need_cols((kn >> 3) + 1)) return;
-        load_ktile(pj + (long long)kn * (BK * 8), voff, ra);
-        load_ktile(pi + (long long)kn * (BK * 8), voff, rb);
-        const char* la = lds + cur * 2 * OPB;                     // rows of panel j
-        const char* lb = la + OPB;                                // rows of panel i (the same rows in a diagonal task)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          dv2 bf = *reinterpret_cast<const dv2*>(lb + (16 * rw + lr) * ROWB + (4 * lq + 2 * hh) * 8);
-          bf.x = -bf.x; bf.y = -bf.y;
-          sfor<0, 2>([&](auto gc) {
-            constexpr int G = decltype(gc)::value;
-            dv2 af[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-              af[x] = *reinterpret_cast<const dv2*>(la + (16 * (4 * G + x) + lr) * ROWB + (4 * lq + 2 * hh) * 8);
-            sfor<0, 4>([&](auto xc) {
-              constexpr int KB = 4 * G + decltype(xc)::value;
-              S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].x, bf.x, S[KB], 0, 0, 0);
-              S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].y, bf.y, S[KB], 0, 0, 0);
-            });
+      sfor<0, 8>([&](auto jc) {
+        constexpr int JB = decltype(jc)::value;
+        double* lc = lcol + (JB & 1) * 8 * BLK;                     // block column JB of L
+        // ---- phase A: one wave factors the diagonal block; the others apply block column C = JB - 1:
+        //      S[X] -= L(X, C) * S[C] for X = C + 1 .. rw (factor rows) or C + 1 .. 7 (inverse columns, rw <= C)
+        if (rw == JB) {
+          const int bad = gpk_p2_factor(dblk, BS, lc + JB * BLK, BS, wd + JB * BLK, BS, lane, S);
+          if (bad != 0 && lane == 0) atomicCAS(info, 0, p.row0 + TS * j + 16 * JB + bad);
+          if (lane < 16) {                                          // L_bb: lower triangle only (the tile's upper part stays)
+            double* dst = Atile + (long long)(16 * JB + lane) * lda + 16 * JB;
+  #pragma unroll
+            for (int c = 0; c < 16; ++c)
+              if (c <= lane) dst[c] = lc[JB * BLK + lane * BS + c];
+          }
+  #pragma unroll
+          for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
+        } else if constexpr (JB > 0) {
+          constexpr int C = JB - 1;
+          const double* pc = lcol + (C & 1) * 8 * BLK;
+          const int hi = rw > C ? rw : 7;
+          const d4 nb = -S[C];
+          double an[4];
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) an[t] = pc[(C + 1) * BLK + lr * BS + lq + 4 * t];
+          sfor<C + 1, 8>([&](auto xc) {
+            constexpr int X = decltype(xc)::value;
+            double ac[4];
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) ac[t] = an[t];
+            if constexpr (X < 7) {
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) an[t] = pc[(X + 1) * BLK + lr * BS + lq + 4 * t];
+            }
+            if (X <= hi && !(X == C + 1 && rw == C + 1)) {
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) S[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], nb[t], S[X], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           });
         }
         __syncthreads();
-      }
-    }
-
-    PT_STAMP(1);
-    if (!diag) {
-      // =================================================== off-diagonal task: X^T = W_jj X^^T, in place, then publish
-      if (tid == 0) ctl[1] = poll_ready(ready + j, nullptr, j + 1, abortp);
-      __syncthreads();
-      if (ctl[1] < 0) return;
-      PT_STAMP(2);
-      const int ta = fresh_tid(), lr = ta & 15, lq = (ta >> 4) & 3;
-      double* wl = reinterpret_cast<double*>(lds);
-      {
-        // the 36 lower blocks of W_jj (128 x 128 row-major) -> block-major LDS image, block (mb, kb) at mb (mb + 1) / 2 + kb
-        const double* wj = Wv + (long long)j * TS * TS;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(wj), 0, 0x7fffffff, 0x00020000);
-        V16 v[9];                                                 // all nine 16-byte pieces of a thread in flight at once
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          const int e = ta + NT * u, blk = e >> 7, rowb = (e & 127) >> 3, cp = e & 7;
-          int mb = 0;
-          while ((mb + 1) * (mb + 2) / 2 <= blk) ++mb;
-          const int kb = blk - mb * (mb + 1) / 2;
-          v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((16 * mb + rowb) * TS + 16 * kb + 2 * cp) * 8), 0, 16);
+        PT_STAMP(2 + JB);
+        // ---- phase B: S[JB] <- W_bb * S[JB]: below the diagonal block that is L(rw, JB)^T, in the columns of the inverse
+        //      W(JB, rw); the wave of the diagonal block itself takes W_bb as it stands
+        if (rw == JB) {
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) S[JB][t] = wd[JB * BLK + lr * BS + lq + 4 * t];
+        } else {
+          S[JB] = blk_mfma<true>(wd + JB * BLK, S[JB], d4{0.0, 0.0, 0.0, 0.0}, lr, lq);
         }
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          const int e = ta + NT * u, blk = e >> 7, rowb = (e & 127) >> 3, cp = e & 7;
-          const dv2 d = __builtin_bit_cast(dv2, v[u]);
-          wl[blk * BLK + rowb * BS + 2 * cp] = d.x;
-          wl[blk * BLK + rowb * BS + 2 * cp + 1] = d.y;
+        if (rw > JB) {
+          double* dst = Atile + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            lc[rw * BLK + lr * BS + lq + 4 * t] = S[JB][t];
+            dst[4 * t] = S[JB][t];
+          }
+        } else {
+          double* dst = Wj + (long long)(16 * JB + lq) * TS + 16 * rw + lr;
+  #pragma unroll
+          for (int t = 0; t < 4; ++t)
+            __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-      }
-      __syncthreads();
-      PT_STAMP(3);
-      sfor<0, 8>([&](auto mc) {
-        constexpr int MB = 7 - decltype(mc)::value;               // descending: block MB needs the OLD blocks 0 .. MB only
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        sfor<0, MB + 1>([&](auto kc) {
-          constexpr int KB = decltype(kc)::value;
-          acc = blk_mfma<false>(wl + (MB * (MB + 1) / 2 + KB) * BLK, S[KB], acc, lr, lq);
-        });
-        S[MB] = acc;
-      });
-      PT_STAMP(4);
-      __syncthreads();                                            // every wave is done with the W image
-      // S[mb][t] (lane n = lr, q = lq) = L_ij[16 w + n][16 mb + q + 4 t]: through LDS in two column halves, then
-      // whole 512-byte row pieces with 16-byte sc1 stores
-      double* ob = reinterpret_cast<double*>(lds);
-      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(Atile, 0, 0x7fffffff, 0x00020000);
-      sfor<0, 2>([&](auto hc) {
-        constexpr int hf = decltype(hc)::value;
-        sfor<0, 4>([&](auto mc) {
-          constexpr int ML = decltype(mc)::value;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) ob[(16 * wave + lr) * OS + 16 * ML + lq + 4 * t] = S[ML + 4 * hf][t];
-        });
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = ta + NT * u, row = e >> 5, c2 = e & 31;
-          const V16 v = *reinterpret_cast<const V16*>(ob + row * OS + 2 * c2);
-          __builtin_amdgcn_raw_buffer_store_b128(v, ro, (unsigned)(((long long)row * lda + 64 * hf + 2 * c2) * 8), 0, 16);
+        // ---- the wave of the next diagonal block goes on at once: the block's last update needs only the L block this
+        //      wave has just written, then it goes to LDS for the factoring sweep
+        if constexpr (JB < 7) {
+          if (rw == JB + 1) {
+            const d4 nb = -S[JB];
+            S[JB + 1] = blk_mfma<false>(lc + (JB + 1) * BLK, nb, S[JB + 1], lr, lq);
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[JB + 1][t];
+          }
         }
         __syncthreads();
       });
       wait_vm0();
       __syncthreads();
-      if (tid == 0) st_agent(ready + i, j + 1);
-      PT_STAMP(5);
-      continue;
-    }
-
-    // ======================================================= diagonal task: L_jj and W_jj = L_jj^-1 from the accumulators
-    // Slot S[k] of the wave that owns block row / column rw:  k <= rw: block (rw, k) of the updated tile, transposed,
-    // until block column k is final (then L(rw, k)^T, needed for one more step);  k >= rw: block (k, rw) of the forward
-    // substitution for the inverse (R = -sum L W, then W(k, rw)).  Slot rw changes hands when the wave's own diagonal
-    // block has gone to the factoring wave.
-    const int tl = fresh_tid(), lane = tl & 63, lr = tl & 15, lq = (tl >> 4) & 3;
-    double* dblk = reinterpret_cast<double*>(lds);                // the current diagonal block, row-major
-    double* wd = dblk + BLK;                                      // wd[b][r][c] = W_bb[c][r]
-    double* lcol = wd + 8 * BLK;                                  // two block columns of L: lcol[buf][block row]
-    double* Wj = Wv + (long long)j * TS * TS;
-    int* info = p.info + b;
-    __syncthreads();                                              // the k-loop's last reads of the staging buffers
-    sfor<1, 8>([&](auto kc) {                                     // the blocks right of the diagonal are not part of the task
-      constexpr int KB = decltype(kc)::value;
-      if (KB > rw) S[KB] = d4{0.0, 0.0, 0.0, 0.0};
-    });
-    if (rw == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[0][t];
-    }
-    __syncthreads();
-    sfor<0, 8>([&](auto jc) {
-      constexpr int JB = decltype(jc)::value;
-      double* lc = lcol + (JB & 1) * 8 * BLK;                     // block column JB of L
-      // ---- phase A: one wave factors the diagonal block; the others apply block column C = JB - 1:
-      //      S[X] -= L(X, C) * S[C] for X = C + 1 .. rw (factor rows) or C + 1 .. 7 (inverse columns, rw <= C)
-      if (rw == JB) {
-        const int bad = gpk_p2_factor(dblk, BS, lc + JB * BLK, BS, wd + JB * BLK, BS, lane, S);
-        if (bad != 0 && lane == 0) atomicCAS(info, 0, p.row0 + TS * j + 16 * JB + bad);
-        if (lane < 16) {                                          // L_bb: lower triangle only (the tile's upper part stays)
-          double* dst = Atile + (long long)(16 * JB + lane) * lda + 16 * JB;
-#pragma unroll
-          for (int c = 0; c < 16; ++c)
-            if (c <= lane) dst[c] = lc[JB * BLK + lane * BS + c];
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
-      } else if constexpr (JB > 0) {
-        constexpr int C = JB - 1;
-        const double* pc = lcol + (C & 1) * 8 * BLK;
-        const int hi = rw > C ? rw : 7;
-        const d4 nb = -S[C];
-        double an[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) an[t] = pc[(C + 1) * BLK + lr * BS + lq + 4 * t];
-        sfor<C + 1, 8>([&](auto xc) {
-          constexpr int X = decltype(xc)::value;
-          double ac[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) ac[t] = an[t];
-          if constexpr (X < 7) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) an[t] = pc[(X + 1) * BLK + lr * BS + lq + 4 * t];
-          }
-          if (X <= hi && !(X == C + 1 && rw == C + 1)) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) S[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], nb[t], S[X], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
+      if (tid == 0) {
+        st_agent(ready + j, j + 1);
+        st_agent(pausep, 0);
       }
-      __syncthreads();
-      PT_STAMP(2 + JB);
-      // ---- phase B: S[JB] <- W_bb * S[JB]: below the diagonal block that is L(rw, JB)^T, in the columns of the inverse
-      //      W(JB, rw); the wave of the diagonal block itself takes W_bb as it stands
-      if (rw == JB) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) S[JB][t] = wd[JB * BLK + lr * BS + lq + 4 * t];
-      } else {
-        S[JB] = blk_mfma<true>(wd + JB * BLK, S[JB], d4{0.0, 0.0, 0.0, 0.0}, lr, lq);
+      PT_STAMP(10);
+      if (p.trace && tid == 0) p.trace[(long long)task * 16 + 15] = (long long)__builtin_readcyclecounter();
       }
-      if (rw > JB) {
-        double* dst = Atile + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          lc[rw * BLK + lr * BS + lq + 4 * t] = S[JB][t];
-          dst[4 * t] = S[JB][t];
-        }
-      } else {
-        double* dst = Wj + (long long)(16 * JB + lq) * TS + 16 * rw + lr;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // ---- the wave of the next diagonal block goes on at once: the block's last update needs only the L block this
-      //      wave has just written, then it goes to LDS for the factoring sweep
-      if constexpr (JB < 7) {
-        if (rw == JB + 1) {
-          const d4 nb = -S[JB];
-          S[JB + 1] = blk_mfma<false>(lc + (JB + 1) * BLK, nb, S[JB + 1], lr, lq);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[JB + 1][t];
-        }
-      }
-      __syncthreads();
-    });
-    wait_vm0();
-    __syncthreads();
-    if (tid == 0) st_agent(ready + j, j + 1);
-    PT_STAMP(10);
+      return true;
+    };
+    if (!(diag ? run(IC<1>{}) : run(IC<0>{}))) return;
   }
 }
 
@@ -438,16 +593,17 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   const int nb = h->batch;
   const long long ntasks = (long long)nt * (nt + 1) / 2 * nb;
   const size_t ctrl_ints = 16 + (size_t)nb * nt;
-  if (ntasks >= (1ll << 30) || ctrl_ints > GPK_PTILE_CTRL_INTS) return GPK_OK;
+  if (ntasks >= (1ll << 30) || ctrl_ints > (size_t)PAUSE_OFF) return GPK_OK;
   if (!h->d_ptile) {
     GPK_CHECK_HIP(h, hipSetDevice(h->device));
-    GPK_CHECK_HIP(h, hipMalloc((void**)&h->d_ptile, GPK_PTILE_CTRL_INTS * sizeof(int)));
+    GPK_CHECK_HIP(h, hipMalloc((void**)&h->d_ptile, (GPK_PTILE_CTRL_INTS + 16) * sizeof(int)));
     int cus = 0;
     GPK_CHECK_HIP(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     h->ptile_slots = 2 * (cus > 0 ? cus : 256);
   }
   const long long sA = gpk_bstride(h, A), sW = gpk_bstride(h, winv);
-  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_ptile, 0, ctrl_ints * sizeof(int), h->stream));
+  // (the word behind the control block is the sticky "some launch of this gpk_potrf gave up" flag: zeroed by the first launch)
+  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_ptile, 0, (GPK_PTILE_CTRL_INTS + (h->ptile_launches == 0 ? 1 : 0)) * sizeof(int), h->stream));
   // the part of winv above the block diagonal is never written by the kernel: the tile GEMMs that use winv read whole tiles
   for (int b = 0; b < nb; ++b)
     GPK_CHECK_HIP(h, hipMemsetAsync((char*)winv + b * sW, 0, (size_t)Np * TS * sizeof(double), h->stream));
@@ -460,8 +616,8 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   p.trace = nullptr;
   if (const char* tp = getenv("GPK_PTILE_TRACE")) {        // debugging aid: per-task time stamps to the file named there
     void* ws = nullptr;
-    GPK_TRY(gpk_scratch(h, (size_t)ntasks * 16 * sizeof(long long), &ws));
-    GPK_CHECK_HIP(h, hipMemsetAsync(ws, 0, (size_t)ntasks * 16 * sizeof(long long), h->stream));
+    GPK_TRY(gpk_scratch(h, ((size_t)ntasks * 16 + 64) * sizeof(long long), &ws));
+    GPK_CHECK_HIP(h, hipMemsetAsync(ws, 0, ((size_t)ntasks * 16 + 64) * sizeof(long long), h->stream));
     p.trace = (long long*)ws;
     h->ptile_trace_path = tp;
     h->ptile_trace_n = ntasks;
@@ -469,6 +625,7 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   const unsigned grid = (unsigned)(ntasks < h->ptile_slots ? ntasks : h->ptile_slots);
   hipLaunchKernelGGL(ptile_potrf_kernel, dim3(grid), dim3(NT), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
+  ++h->ptile_launches;
   *used = 1;
   return GPK_OK;
 }
@@ -476,11 +633,15 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
 // after the stream has been synchronised: did the launch give up?
 int gpk_potrf_ptile_check(gpk_handle h) {
   if (!h->ptile_trace_path.empty() && h->scratch) {
-    std::vector<long long> t((size_t)h->ptile_trace_n * 16);
+    std::vector<long long> t((size_t)h->ptile_trace_n * 16 + 64);
     GPK_CHECK_HIP(h, hipMemcpy(t.data(), h->scratch, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(h->ptile_trace_path.c_str(), "w")) {
       for (long long k = 0; k < h->ptile_trace_n; ++k) {
         for (int c = 0; c < 16; ++c) fprintf(f, "%lld ", t[(size_t)k * 16 + c]);
+        fprintf(f, "\n");
+      }
+      for (int r = 0; r < 4; ++r) {           // per-iteration cycle stamps of one diagonal task's last k-step
+        for (int c = 0; c < 16; ++c) fprintf(f, "%lld ", t[(size_t)h->ptile_trace_n * 16 + 16 * r + c]);
         fprintf(f, "\n");
       }
       fclose(f);
@@ -488,7 +649,7 @@ int gpk_potrf_ptile_check(gpk_handle h) {
     h->ptile_trace_path.clear();
   }
   int ab = 0;
-  GPK_CHECK_HIP(h, hipMemcpy(&ab, h->d_ptile + 1, sizeof(int), hipMemcpyDeviceToHost));
+  GPK_CHECK_HIP(h, hipMemcpy(&ab, h->d_ptile + GPK_PTILE_CTRL_INTS, sizeof(int), hipMemcpyDeviceToHost));
   if (ab != 0) {
     h->err = "potrf: the one-launch factorisation timed out waiting for a tile (internal error)";
     return GPK_HIP_ERROR;
