@@ -1,3 +1,4 @@
 cd /root/repo
 timeout -k 10 600 python -m pytest tests/test_gpu_ptile.py -x -q 2>&1 | tail -3
-timeout -k 10 400 python tools/exp_ptile.py 4096 16384 32768 65536 2>&1 | grep N=
+timeout -k 10 300 python tools/exp_ptile.py 1024 2048 4096 8192 16384 2>&1 | grep N=
+timeout -k 10 120 python tools/exp_ptile_trace.py 1024 2>&1 | grep "^D( [2-3]"

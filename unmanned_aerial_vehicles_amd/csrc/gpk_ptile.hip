@@ -497,12 +497,6 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         if (rw == JB) {
           const int bad = gpk_p2_factor(dblk, BS, lc + JB * BLK, BS, wd + JB * BLK, BS, lane, S);
           if (bad != 0 && lane == 0) atomicCAS(info, 0, p.row0 + TS * j + 16 * JB + bad);
-          if (lane < 16) {                                          // L_bb: lower triangle only (the tile's upper part stays)
-            double* dst = Atile + (long long)(16 * JB + lane) * lda + 16 * JB;
-  #pragma unroll
-            for (int c = 0; c < 16; ++c)
-              if (c <= lane) dst[c] = lc[JB * BLK + lane * BS + c];
-          }
   #pragma unroll
           for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
         } else if constexpr (JB > 0) {
@@ -540,26 +534,33 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           S[JB] = blk_mfma<true>(wd + JB * BLK, S[JB], d4{0.0, 0.0, 0.0, 0.0}, lr, lq);
         }
         if (rw > JB) {
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) lc[rw * BLK + lr * BS + lq + 4 * t] = S[JB][t];
+          // ---- the wave of the next diagonal block goes on at once: L(JB + 1, JB)^T in the C/D map is both the A operand
+          //      (lane (m, q), step t: L[m][q + 4 t]) and, negated, the B operand of the block's last update - no LDS round
+          //      trip; then the block goes to LDS for the factoring sweep.  Its stores to memory come after that.
+          if constexpr (JB < 7) {
+            if (rw == JB + 1) {
+  #pragma unroll
+              for (int t = 0; t < 4; ++t)
+                S[JB + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[JB][t], -S[JB][t], S[JB + 1], 0, 0, 0);
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[JB + 1][t];
+            }
+          }
           double* dst = Atile + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
   #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            lc[rw * BLK + lr * BS + lq + 4 * t] = S[JB][t];
-            dst[4 * t] = S[JB][t];
-          }
+          for (int t = 0; t < 4; ++t) dst[4 * t] = S[JB][t];
         } else {
           double* dst = Wj + (long long)(16 * JB + lq) * TS + 16 * rw + lr;
   #pragma unroll
           for (int t = 0; t < 4; ++t)
             __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- the wave of the next diagonal block goes on at once: the block's last update needs only the L block this
-        //      wave has just written, then it goes to LDS for the factoring sweep
-        if constexpr (JB < 7) {
-          if (rw == JB + 1) {
-            const d4 nb = -S[JB];
-            S[JB + 1] = blk_mfma<false>(lc + (JB + 1) * BLK, nb, S[JB + 1], lr, lq);
+          if (rw == JB && lane < 16) {                              // L_bb: lower triangle only (the tile's upper part stays)
+            double* dl = Atile + (long long)(16 * JB + lane) * lda + 16 * JB;
   #pragma unroll
-            for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[JB + 1][t];
+            for (int c = 0; c < 16; ++c)
+              if (c <= lane) dl[c] = lc[JB * BLK + lane * BS + c];
           }
         }
         __syncthreads();
