@@ -678,7 +678,7 @@ def main():
     # ---------------------------------------------------------------- the timed hot path
     kss = sf2 + noise
     ystd2 = torch.as_tensor(y_std ** 2, device=be.device, dtype=torch.float64)
-    assert c4 or dev.fp32_mean_ok(), "the benchmark model must pass the fp32 mean gate (it is served in fp32)"
+    assert c4 or dev.fp32_mean_ok(q32), "the benchmark batch must pass the fp32 mean gate (it is served in fp32)"
 
     def step_c4():
         mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4 only

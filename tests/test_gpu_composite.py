@@ -161,7 +161,7 @@ def test_one_call_serving_step(M):
     assert torch.equal(one, packed)
     # gated: the rows below the re-check fraction of the prior (raised here so that the training points among the queries
     # fall under it) are recomputed in fp64, the others are untouched
-    assert dev.fp32_mean_ok()
+    assert dev.fp32_mean_ok(q)
     dev.FP32_VAR_RECHECK_FRACTION = 0.12
     gated = dev.predict_packed_dev(q, ym, ys, kss, 0.0, "float32", "auto", gated=True)
     low = var < dev.FP32_VAR_RECHECK_FRACTION * kss

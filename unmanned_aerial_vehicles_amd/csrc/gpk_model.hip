@@ -113,7 +113,8 @@ __global__ void square_kernel(const double* __restrict__ a, long long n, double*
 // A2 = max_m sqrt(sum_j (k_mj alpha_j)^2) / max_m |mean_m| is measured on <= 1024 evenly spaced training rows (where it is
 // largest) with two fp64 K4 launches - the second with the squared kernel (length-scales / sqrt 2, sf2^2) and squared
 // weights - once per alpha; a model with c A2 above 1e-4 is served by the fp64 kernels.
-constexpr double F32_MEAN_C_MFMA = 4.0e-7, F32_MEAN_C_VALU = 9.0e-7, F32_MEAN_TOL = 1e-4;
+// (round-4 calibration on batches up to 2^20 queries: profiles/r04_fp32_gate_calibration.log, device.py FP32_MEAN_ERR_PER_AMP)
+constexpr double F32_MEAN_C_MFMA = 7.0e-7, F32_MEAN_C_VALU = 1.1e-6, F32_MEAN_TOL = 1e-4;
 // fp32 variances below this fraction of the prior variance are recomputed in fp64 (their relative error is the absolute
 // error of |W k*|^2 - up to 4e-5 kss - over the variance itself)
 constexpr double F32_VAR_RECHECK_FRACTION = 1e-2;
