@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-4 artifacts from ONE GPU box (everything lands under gpurun_out/final4/; copy what is judged into profiles/).
+set -o pipefail
+out=gpurun_out/final4; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log
+python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/prof.err
+cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv; rm -rf $out/prof
+python bench.py --workload lml > $out/bench_lml.json 2> $out/bench_lml.err; echo "lml rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --workload lml --no-cpu-baseline > $out/bench_lml_under_rocprof.json 2> $out/prof_lml.err
+cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/lml_kernel_stats.csv; rm -rf $out/prof
+python bench.py --workload train > $out/bench_train.json 2> $out/bench_train.err; echo "train rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --workload train --no-cpu-baseline --steps 1 --warmup 1 > $out/bench_train_under_rocprof.json 2> $out/prof_train.err
+cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/train_kernel_stats.csv; rm -rf $out/prof
+python bench.py --workload c4 --steps 5 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 rc=$?"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "torchrun rc=$?"
+(echo "# tools/exp_ptile.py: gpk_potrf by the recursive launch chain (ptile = 0) against the one-launch tile factorisation, same matrix, same box"; python tools/exp_ptile.py 512 1024 2048 4096 8192 16384 32768 2>&1 | grep N=) > $out/ptile_ab.log; cat $out/ptile_ab.log
+python tools/exp_ptile_trace.py 1024 2>&1 | grep -v amdgpu > $out/ptile_trace_1024.log
+python tools/exp_ptile_trace.py 4096 2>&1 | grep -v amdgpu > $out/ptile_trace_4096.log; head -8 $out/ptile_trace_4096.log
+python -u tools/run_configs.py > $out/run_configs.log 2>&1; echo "run_configs rc=$?"
