@@ -602,11 +602,14 @@ def main():
             # timed region (a first hipMalloc of this size takes up to a second on some boxes and is not kernel time)
             # (the fp16 x 2 operand is split straight from the fp64 inverse factor: no fp32 copy exists on that route;
             # the trtri scratch is gone again before the split operand is allocated, as in DeviceGP)
+            # (in the order and with the lifetimes the product path has: the split operand is allocated while the inverse
+            # factor is alive and after its scratch has gone - freed FIRST here, the 34 GB block would be cut up to serve
+            # the 17 GB request and the timed region would pay a fresh hipMalloc of 17 GB, 0.5 s, for the split operand)
             warm = [be.empty((dev.Np, dev.Np), torch.float64), be.empty(((dev.Np // 2 + 128) ** 2,), torch.float64)]
             if method != "inverse_split2":
                 warm.append(be.empty((dev.Np, dev.Np), torch.float32))
-            del warm
-            warm = be.empty((dev.Np * dev.Np * 4,), torch.uint8)
+            warm.pop(1)
+            warm.append(be.empty((dev.Np * dev.Np * (6 if method == "inverse_split" else 4),), torch.uint8))
             del warm
             torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -648,6 +651,7 @@ def main():
                                  "inverse": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy",
                                  "solve": "fp32 copy of L"}[method],
                "variance_prep_s": prep_s, "trtri_s": trtri_s,
+               "variance_split_ms": ((prep_s - trtri_s) * 1e3) if trtri_s else None,    # block maxima + split: two passes over W
                "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None,
                "replicated_per_rank": world > 1}
         return dev, fit

@@ -28,6 +28,8 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_GEMM_WM_F64")) h->gemm_wm_f64 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
   if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
+  if (const char* e = getenv("GPK_GEMM_BALANCED")) h->gemm_balanced = atoi(e);
+  if (const char* e = getenv("GPK_GEMM_BALANCED_MAX")) h->gemm_balanced_max_tiles = atoll(e);
   if (const char* e = getenv("GPK_K5_SUPER")) h->k5_super = atoi(e);
   if (const char* e = getenv("GPK_K5_SPLIT2_TILE")) { const int v = atoi(e); h->k5_split2_tile = (v >= 0 && v <= 2) ? v : 0; }
   if (const char* e = getenv("GPK_SMALL_PATH")) h->small_path = atoi(e);
@@ -88,6 +90,8 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "trsm256") h->trsm256 = value;
   else if (n == "trtri_levels") h->trtri_levels = value;
   else if (n == "gemm_small_tiles") h->gemm_small_tiles = value;
+  else if (n == "gemm_balanced") h->gemm_balanced = value;
+  else if (n == "gemm_balanced_max_tiles") h->gemm_balanced_max_tiles = value;
   else if (n == "k3_stream_min_np") h->k3_stream_min_np = value;
   else if (n == "ptile") h->ptile = value;
   else if (n == "ptile_max_np") h->ptile_max_np = value;

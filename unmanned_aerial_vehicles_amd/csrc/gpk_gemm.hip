@@ -36,6 +36,9 @@ struct KParams {
   int heavy_first;            // reverse the tile-row order (k-range grows with the row: longest tiles first)
   int k_super;
   int direct, nst, nsc, sr;   // tile mapping: direct grid, or super-tiles (count, per super-row, rows)
+  // balanced persistent schedule (launches whose tiles differ in k-range): bal_wg resident workgroups, bal_tiles tiles per
+  // problem enumerated longest k-range first (rows or columns primary, ascending or descending), bal_ny problems
+  int balanced, bal_wg, bal_tiles, bal_ny, bal_rows, bal_asc;
 };
 
 typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
@@ -319,9 +322,46 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   // dispatch, verified with HW_REG_XCC_ID), so an XCD walks the 64 tiles of one super-tile with its 64 resident
   // workgroups: the 8 + 8 operand panels of a super-tile are shared through that XCD's L2, and every XCD sees
   // an even sample of the tile grid (triangular problems stay balanced).
+  // Balanced persistent schedule: a launch whose tiles differ in k-range (triangular operands) and that fits a few
+  // residency rounds is bound by where its longest tiles land - resident together on one CU they share its matrix pipe,
+  // and a long tile that starts late is the tail of the launch.  Here the tiles are enumerated longest first and dealt to
+  // bal_wg resident workgroups in serpentine order (sweep s: positions s W + w going up, then (s + 1) W - 1 - w going
+  // down): every workgroup walks a list of the same total length, whatever CU it runs on.  Workgroup ids are dealt
+  // round-robin to the XCDs, so w is remapped to give each XCD runs of 8 consecutive positions out of every 64
+  // (neighbouring tiles share an operand panel in that XCD's L2; every XCD still samples the whole weight range of a
+  // sweep - a contiguous eighth per XCD measured 20 % slower on one-sweep launches, whose heaviest eighth then sits on
+  // one XCD).  Per-tile arithmetic is unchanged: results are bit-identical to the static mapping.
+  for (int sweep = 0;; ++sweep) {
   int tm, tn;
+  long long by = blockIdx.y;
   int rlo = -1, rhi = -1, clo = -1, chi = -1;   // k_super: extreme tile rows / columns of the super-tile
-  if (p.direct) {
+  if (p.balanced) {
+    const long long total = (long long)p.bal_tiles * p.bal_ny;
+    if ((long long)sweep * p.bal_wg >= total) return;
+    const int w = (int)(blockIdx.x >> 6) * 64 + (int)(blockIdx.x & 7) * 8 + (int)((blockIdx.x >> 3) & 7);
+    const long long pos = (sweep & 1) ? (long long)(sweep + 1) * p.bal_wg - 1 - w : (long long)sweep * p.bal_wg + w;
+    if (pos >= total) continue;
+    by = pos % p.bal_ny;
+    int q = (int)(pos / p.bal_ny);
+    if (p.lower_only) {
+      if (!p.bal_asc) q = p.bal_tiles - 1 - q;
+      int r = (int)((__builtin_sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+      while ((r + 1) * (r + 2) / 2 <= q) ++r;
+      while (r * (r + 1) / 2 > q) --r;
+      tm = r;
+      tn = q - r * (r + 1) / 2;
+    } else if (p.bal_rows) {
+      const int r = q / p.ntn;
+      tn = q - r * p.ntn;
+      tm = p.bal_asc ? r : p.ntm - 1 - r;
+    } else {
+      const int c = q / p.ntm;
+      tm = q - c * p.ntm;
+      tn = p.bal_asc ? c : p.ntn - 1 - c;
+    }
+  } else if (sweep > 0) {
+    return;
+  } else if (p.direct) {
     tm = blockIdx.x % p.ntm;
     tn = blockIdx.x / p.ntm;
   } else {
@@ -398,7 +438,7 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     }
     if (p.k_super && p.heavy_first) { const int a0 = p.ntm - 1 - rhi, a1 = p.ntm - 1 - rlo; rlo = a0; rhi = a1; }
   }
-  if (p.heavy_first) tm = p.ntm - 1 - tm;
+  if (p.heavy_first && !p.balanced) tm = p.ntm - 1 - tm;
   if (rlo < 0) { rlo = rhi = tm; clo = chi = tn; }
   if (p.lower_only && tn > tm) return;
 
@@ -411,7 +451,6 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   ke = min(ke, p.k);
   const int nkt = (ke - kb) / BK;
 
-  const long long by = blockIdx.y;
   const T* A = reinterpret_cast<const T*>(p.A + by * p.sA);
   const T* B = reinterpret_cast<const T*>(p.B + by * p.sB);
   T* C = reinterpret_cast<T*>(p.C + by * p.sC);
@@ -476,6 +515,8 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     // the k-loop ended with a barrier: the staging buffers are free for the reduction
     sumsq_acc<AB, NB, WM, TS>(lds, reinterpret_cast<double*>(C), p.ldc, tm, col0, wm, col_w, lane, tid, acc,
                               p.alpha);
+    __syncthreads();            // (the reduction used the staging buffers: the next tile of a persistent walk refills them)
+  }
   }
 }
 
@@ -510,8 +551,31 @@ int launch(gpk_handle h, const GemmArgs& g) {
   // k_super widens a tile's k-range to that of its super-tile, which spans at most two bands of sr tile rows:
   // allowed only while that stays inside the zero band the producers of triangular operands guarantee
   p.k_super = (g.k_super && 2 * p.sr * (TS / 64) <= 2 * GPK_ZERO_BAND_TILES) ? 1 : 0;
-  const long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
+  long long nblocks = p.direct ? (long long)p.ntm * p.ntn : (long long)((p.nst + 7) / 8) * 512;
   if (nblocks >= (1ll << 31)) { h->err = "gemm: grid too large"; return GPK_BAD_ARG; }
+  // Tiles that differ in k-range, few enough residency rounds for the placement of the long ones to matter: the balanced
+  // persistent schedule (see the kernel).  dr / dc: how a tile's k-length changes per tile row / column.
+  p.balanced = 0; p.bal_wg = 0; p.bal_tiles = 0; p.bal_ny = 1; p.bal_rows = 0; p.bal_asc = 0;
+  {
+    const int dr = (g.ke0 < 0 ? 0 : g.ke_row) - g.kb_row, dc = (g.ke0 < 0 ? 0 : g.ke_col) - g.kb_col;
+    const long long total = ntiles * ny;
+    if (h->gemm_balanced && (dr != 0 || (dc != 0 && !g.lower_only)) && total <= h->gemm_balanced_max_tiles) {
+      if (h->cus <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
+        h->cus = cus;
+      }
+      const long long resident = (long long)h->cus * (TS == 128 ? 2 : 4) / 64 * 64;
+      p.balanced = 1;
+      p.bal_wg = (int)(total < resident ? (total + 63) / 64 * 64 : resident);
+      p.bal_tiles = (int)ntiles;
+      p.bal_ny = (int)ny;
+      p.bal_rows = (dr != 0 || g.lower_only) ? 1 : 0;
+      p.bal_asc = (dr != 0 ? dr < 0 : dc < 0) ? 1 : 0;
+      nblocks = p.bal_wg;
+      ny = 1;
+    }
+  }
   dim3 grid((unsigned)nblocks, ny), block(WM * 128);
   if (g.epilogue == 1) {
     if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }

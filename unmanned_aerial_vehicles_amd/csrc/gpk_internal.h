@@ -36,6 +36,9 @@ struct gpk_context {
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 1024;   // launches with fewer 128 x 128 tiles than this run on 64 x 64 tiles (GPK_GEMM_SMALL)
+  int gemm_balanced = 1;         // launches whose tiles differ in k-range: balanced persistent tile schedule (GPK_GEMM_BALANCED=0: static)
+  long long gemm_balanced_max_tiles = 32768;   // ... up to this many tiles per launch (all problems of a batch)
+  int cus = 0;                   // compute units of the device (read once)
   int trtri_levels = 1;      // gpk_trtri: one batched launch per level for power-of-two tile counts (GPK_TRTRI_LEVELS=0: recursion)
   int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
