@@ -30,7 +30,7 @@ def join(out):
     prev = t0
     agg = {}
     for name, s, e in g:
-        short = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:48]
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
         if "<" in name and "gemm_kernel" in name:
             short = name[name.index("gemm_kernel"):][:44]
         a = agg.setdefault(short, [0, 0.0])

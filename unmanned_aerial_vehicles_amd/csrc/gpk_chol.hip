@@ -293,9 +293,10 @@ __global__ void to_f32_kernel(const double* __restrict__ a, long long n, float* 
   if (e < n) b[e] = (float)a[e];
 }
 __global__ void copy_leaf_kernel(const double* __restrict__ w0, double* __restrict__ W0, long long ldw,
-                                 long long stride_w, long long stride_W) {
-  const double* __restrict__ w = reinterpret_cast<const double*>(reinterpret_cast<const char*>(w0) + blockIdx.y * stride_w);
-  double* __restrict__ W = reinterpret_cast<double*>(reinterpret_cast<char*>(W0) + blockIdx.y * stride_W);
+                                 long long stride_w, long long stride_W, long long stride_w2, long long stride_W2) {
+  const double* __restrict__ w = reinterpret_cast<const double*>(reinterpret_cast<const char*>(w0) + blockIdx.y * stride_w +
+                                                                 blockIdx.z * stride_w2);
+  double* __restrict__ W = reinterpret_cast<double*>(reinterpret_cast<char*>(W0) + blockIdx.y * stride_W + blockIdx.z * stride_W2);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= NB * NB) return;
   const int i = e >> 7, j = e & 127;
@@ -646,7 +647,7 @@ int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const doubl
               double* T, int64_t ldt) {
   if (n == NB) {
     hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, h->batch), dim3(256), 0, h->stream, winv, W,
-                       (long long)ldw, gpk_bstride(h, winv), gpk_bstride(h, W));
+                       (long long)ldw, gpk_bstride(h, winv), gpk_bstride(h, W), 0ll, 0ll);
     GPK_LAUNCH_CHECK(h);
     return GPK_OK;
   }
@@ -666,19 +667,27 @@ int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const doubl
   return gpk_gemm(h, GPK_F64, g2);
 }
 
-// Level by level instead of depth first, for a power-of-two number of tiles: the Np / n diagonal blocks of one
-// level are independent, so each level is ONE batched launch per product (and the leaves one copy launch) instead of
-// Np / n launches of a few tiles each -- 2 log2(Np / 128) + 1 launches in total (N = 4096: 11 instead of 94).
+// Level by level instead of depth first: the diagonal blocks of one level are independent, so each level is ONE batched
+// launch per product (and the leaves one copy launch) instead of Np / n launches of a few tiles each.  Blocks of
+// n = 256, 512, ... rows are formed bottom-up from pairs of finished n / 2 blocks; when the tile count is not a power of
+// two the rows behind the last whole block form a ragged tail block that is merged with a whole n / 2 block whenever the
+// tail grows past n / 2 (one more pair of launches at that level).  2 log2(Np / 128) + 1 launches for a power of two
+// (N = 4096: 11 instead of 94), at most twice that otherwise (N = 10 000, 79 tiles: 23 instead of 158).  With the
+// handle in batched mode every launch covers all problems of the batch.
+// T: scratch of at least (Np / 2 + 128)^2 doubles (per problem); a launch lays it out with its own leading dimension.
 int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const double* winv, double* W, int64_t ldw,
-                 double* T, int64_t ldt) {
+                 double* T) {
   const int64_t nl = Np / NB;
-  hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, (unsigned)nl), dim3(256), 0, h->stream, winv, W, (long long)ldw,
-                     (long long)(NB * NB * sizeof(double)), (long long)(NB * (ldw + 1) * sizeof(double)));
+  hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, (unsigned)nl, (unsigned)h->batch), dim3(256), 0, h->stream, winv, W,
+                     (long long)ldw, (long long)(NB * NB * sizeof(double)), (long long)(NB * (ldw + 1) * sizeof(double)),
+                     gpk_bstride(h, winv), gpk_bstride(h, W));
   GPK_LAUNCH_CHECK(h);
-  for (int64_t n = 2 * NB; n <= Np; n *= 2) {
-    const int64_t h2 = n / 2, nb = Np / n;
-    // T_b (h2 x h2) = L21_b * W11_b   (W11 lower: k >= column tile start)
-    GemmArgs g = gemm_args(L + h2 * ldl, ldl, 0, W, ldw, 1, T, ldt, (int)h2, (int)h2, (int)h2, 1.0, 0.0);
+  // one merge: rows [r0, r0 + mt) x columns [c0, c0 + h2) of W from the finished blocks W11 = W[c0.., c0..] (h2 x h2)
+  // and W22 = W[r0.., r0..] (mt x mt), r0 = c0 + h2; `nb` such merges n rows apart
+  auto merge = [&](int64_t c0, int64_t h2, int64_t mt, int64_t n, int64_t nb) -> int {
+    const int64_t r0 = c0 + h2, ldt = nb * h2;
+    // T_b (mt x h2) = L21_b * W11_b   (W11 lower: k >= column tile start)
+    GemmArgs g = gemm_args(L + r0 * ldl + c0, ldl, 0, W + c0 * ldw + c0, ldw, 1, T, ldt, (int)mt, (int)h2, (int)h2, 1.0, 0.0);
     g.kb_col = NB;
     g.k_super = 1;
     g.nbatch = (int)nb;
@@ -687,7 +696,7 @@ int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const d
     g.sC = (long long)(h2 * sizeof(double));             // block b's scratch: columns [b h2, (b + 1) h2) of T
     GPK_TRY(gpk_gemm(h, GPK_F64, g));
     // W21_b = -W22_b * T_b            (W22 lower: k < row tile end)
-    GemmArgs g2 = gemm_args(W + h2 * ldw + h2, ldw, 0, T, ldt, 1, W + h2 * ldw, ldw, (int)h2, (int)h2, (int)h2, -1.0, 0.0);
+    GemmArgs g2 = gemm_args(W + r0 * ldw + r0, ldw, 0, T, ldt, 1, W + r0 * ldw + c0, ldw, (int)mt, (int)h2, (int)mt, -1.0, 0.0);
     g2.ke0 = NB; g2.ke_row = NB;
     g2.k_super = 1;
     g2.heavy_first = 1;
@@ -695,7 +704,12 @@ int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const d
     g2.sA = (long long)(n * (ldw + 1) * sizeof(double));
     g2.sB = (long long)(h2 * sizeof(double));
     g2.sC = (long long)(n * (ldw + 1) * sizeof(double));
-    GPK_TRY(gpk_gemm(h, GPK_F64, g2));
+    return gpk_gemm(h, GPK_F64, g2);
+  };
+  for (int64_t n = 2 * NB; n / 2 < Np; n *= 2) {
+    const int64_t h2 = n / 2, nb = Np / n, rem = Np - nb * n;
+    if (nb > 0) GPK_TRY(merge(0, h2, h2, n, nb));
+    if (rem > h2) GPK_TRY(merge(nb * n, h2, rem - h2, n, 1));     // the tail: a whole n / 2 block and what was behind it
   }
   return GPK_OK;
 }
@@ -832,9 +846,7 @@ extern "C" int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl,
     GPK_LAUNCH_CHECK(h);
   }
   const int64_t n1 = half_split(Np);
-  const int64_t nl = Np / NB;
-  if (h->batch == 1 && nl >= 2 && (nl & (nl - 1)) == 0 && h->trtri_levels)
-    return trtri_levels(h, L, ldl, Np, winv, W, ldw, work, n1);
+  if (Np >= 2 * NB && h->trtri_levels) return trtri_levels(h, L, ldl, Np, winv, W, ldw, work);
   return trtri_rec(h, L, ldl, Np, winv, W, ldw, work, n1 > 0 ? n1 : NB);
 }
 

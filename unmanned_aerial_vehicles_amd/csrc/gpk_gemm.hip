@@ -28,7 +28,9 @@ struct KParams {
   const char* B;
   char* C;
   long long lda, ldb, ldc;  // in elements
-  long long sA, sB, sC;     // byte strides between the problems of a batch (blockIdx.y)
+  long long sA, sB, sC;     // byte strides between the nb1 products of an explicit batch (GemmArgs::nbatch) ...
+  long long hA, hB, hC;     // ... and between the problems of the handle's batched mode: problem index = e + nb1 * hb
+  int nb1;
   int m, n, k;
   double alpha, beta;
   int lower_only, kb0, kb_row, kb_col, ke0, ke_row, ke_col;   // k-range coefficients per 128-row tile index
@@ -451,9 +453,10 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   ke = min(ke, p.k);
   const int nkt = (ke - kb) / BK;
 
-  const T* A = reinterpret_cast<const T*>(p.A + by * p.sA);
-  const T* B = reinterpret_cast<const T*>(p.B + by * p.sB);
-  T* C = reinterpret_cast<T*>(p.C + by * p.sC);
+  const long long be = by % p.nb1, bh = by / p.nb1;
+  const T* A = reinterpret_cast<const T*>(p.A + be * p.sA + bh * p.hA);
+  const T* B = reinterpret_cast<const T*>(p.B + be * p.sB + bh * p.hB);
+  T* C = reinterpret_cast<T*>(p.C + be * p.sC + bh * p.hC);
   const int row0 = tm * TS, col0 = tn * TS;
 
   typename AccT<T, WM, TS>::type acc;
@@ -525,11 +528,12 @@ int launch(gpk_handle h, const GemmArgs& g) {
   KParams p;
   p.A = (const char*)g.A; p.B = (const char*)g.B; p.C = (char*)g.C;
   p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
-  p.sA = gpk_bstride(h, g.A); p.sB = gpk_bstride(h, g.B); p.sC = gpk_bstride(h, g.C);
+  p.hA = gpk_bstride(h, g.A); p.hB = gpk_bstride(h, g.B); p.hC = gpk_bstride(h, g.C);
+  p.sA = p.sB = p.sC = 0;
+  p.nb1 = 1;
   unsigned ny = (unsigned)h->batch;
   if (g.nbatch > 0) {
-    if (h->batch != 1) { h->err = "gemm: explicit batches are not available in batched mode"; return GPK_BAD_ARG; }
-    ny = (unsigned)g.nbatch; p.sA = g.sA; p.sB = g.sB; p.sC = g.sC;
+    p.nb1 = g.nbatch; ny *= (unsigned)g.nbatch; p.sA = g.sA; p.sB = g.sB; p.sC = g.sC;
   }
   p.m = g.m; p.n = g.n; p.k = g.k;
   p.alpha = g.alpha; p.beta = g.beta;
@@ -598,6 +602,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
 int gpk_gemm_tile(gpk_handle h, const GemmArgs& g) {
   long long t128 = g.lower_only ? (long long)(g.m / 128) * (g.m / 128 + 1) / 2 : (long long)(g.m / 128) * (g.n / 128);
   if (g.nbatch > 0) t128 *= g.nbatch;                  // what counts is how many workgroups the launch has
+  t128 *= h->batch;
   const bool aliased = g.C == g.A || g.C == g.B;
   return (!aliased && t128 < h->gemm_small_tiles) ? 64 : 128;
 }

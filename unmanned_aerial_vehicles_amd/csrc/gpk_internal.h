@@ -159,7 +159,7 @@ struct GemmArgs {
                     // zero beyond each row's own range): the 64 workgroups of a super-tile then run in lockstep
   int epilogue;   // 0: store C;  1: C (fp64, ld = ldc) [tile_row][col] = sum over the tile's rows of (alpha*acc)^2
   // nbatch > 0: that many independent products in one launch (second grid dimension), operand i at base + i * stride
-  // (bytes).  Not combinable with the handle's own batched mode.
+  // (bytes); in the handle's batched mode every problem of the batch runs all of them.
   int nbatch;
   long long sA, sB, sC;
 };
