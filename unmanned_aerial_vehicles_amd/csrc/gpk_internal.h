@@ -48,6 +48,9 @@ struct gpk_context {
                              // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
   int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 512 <= Np <= ptile_max_np (GPK_PTILE=0: recursion)
   int ptile_max_np = 16384;
+  int ptile_prog_max_nt = 128;  // ... up to this many tile columns the two tiles under a diagonal tile follow that tile's factorisation 16
+                             // columns at a time instead of waiting for the whole inverse (GPK_PTILE_PROG_NT; 0: never)
+  int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so (GPK_PTILE_PROG_ROWS)
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
   int ptile_launches = 0;    // one-launch factorisations issued by the current gpk_potrf (their abort words are checked at its end)
@@ -103,7 +106,9 @@ struct gpk_context {
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
 
 // ---- one-launch tile Cholesky (gpk_ptile.hip) -----------------------------------------
-constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row counters; one pause word per CU
+constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 2 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
+                                                        // counters; one pause word per CU; per tile row: 16-column steps of the diagonal
+                                                        // tile / of the tile left of it published so far
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
 int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used);
 int gpk_potrf_ptile_check(gpk_handle h);
