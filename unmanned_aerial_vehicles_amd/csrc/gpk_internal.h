@@ -106,9 +106,9 @@ struct gpk_context {
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
 
 // ---- one-launch tile Cholesky (gpk_ptile.hip) -----------------------------------------
-constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 2 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
+constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 3 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
                                                         // counters; one pause word per CU; per tile row: 16-column steps of the diagonal
-                                                        // tile / of the tile left of it published so far
+                                                        // tile / of the tile left of it / of the tile left of that one published so far
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
 int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used);
 int gpk_potrf_ptile_check(gpk_handle h);

@@ -59,6 +59,7 @@ constexpr long long GPK_PTILE_TIMEOUT_TICKS = 400000000ll;   // 4 s of s_memreal
 constexpr int PAUSE_OFF = 16 + 8 * 512;       // ctrl ints: one word per compute unit (key < 1024)
 constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "block rows 0 .. v - 1 of L_jj and their W_bb are final"
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
+constexpr int YPROG_OFF = XPROG_OFF + 8 * 512; // ctrl ints: per tile row i, likewise for tile (i, i - 2)
 constexpr int XS = 18;                        // row stride (doubles) of a wave's 16 x 16 output staging block
 static_assert((18 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: two images and the waves' staging blocks");
 
@@ -123,6 +124,24 @@ __device__ int poll_ktiles(const int* ready, const int* xprog, int j, int need, 
     const int r = ld_agent(ready);
     int v = 8 * min(r, j);
     if (r == j - 1) v += min(ld_agent(xprog), 8);
+    if (v >= need) return v;
+    if ((it & 31) == 31) {
+      if (ld_agent(abortp) != 0) return -1;
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GPK_PTILE_TIMEOUT_TICKS) { st_agent(abortp, 1); st_agent(abortp + (GPK_PTILE_CTRL_INTS - 1), 1); return -1; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// the same for a task that multiplies two row panels: the k-tiles final in both (xa / xb may be null: whole columns only)
+__device__ int poll_ktiles2(const int* ra, const int* xa, const int* rb, const int* xb, int j, int need, int* abortp) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0;; ++it) {
+    const int a = ld_agent(ra), bq = ld_agent(rb);
+    int va = 8 * min(a, j), vb = 8 * min(bq, j);
+    if (a == j - 1 && xa) va += min(ld_agent(xa), 8);
+    if (bq == j - 1 && xb) vb += min(ld_agent(xb), 8);
+    const int v = min(va, vb);
     if (v >= need) return v;
     if ((it & 31) == 31) {
       if (ld_agent(abortp) != 0) return -1;
@@ -213,6 +232,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     int* ready = p.ctrl + 16 + b * nt;
     int* wprog = p.ctrl + PROG_OFF + b * nt + j;     // diagonal tile j of problem b: 16-column steps published so far
     int* xprog = p.ctrl + XPROG_OFF + b * nt + i;    // tile (i, i - 1): 16-column blocks published so far
+    int* yprog = p.ctrl + YPROG_OFF + b * nt + i;    // tile (i, i - 2): likewise
     const long long lda = p.lda;
     double* Atile = A + (long long)i * TS * lda + (long long)j * TS;
     const bool diag = (i == j);
@@ -355,7 +375,25 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           voff[0] = (unsigned)(((long long)rr * lda + c * 2) * 8);
           voff[1] = (unsigned)(((long long)(rr + 64) * lda + c * 2) * 8);
         }
-        if (!need_cols(1)) return false;
+        // (a task that follows its diagonal tile takes the last tile column of its two panels - the tiles of the two tasks that
+        // followed the previous diagonal tile - k-tile by k-tile as they are published, like the diagonal task above)
+        int availk = 0;
+        auto need_kt = [&](int need) -> bool {          // uniform; false = aborted
+          if constexpr (!PROG) {
+            return need_cols(((need - 1) >> 3) + 1);
+          } else {
+            if (availk >= need) return true;
+            if (tid == 0)
+              ctl[1] = poll_ktiles2(ready + i, i == j + 1 ? yprog : nullptr, ready + j, p.ctrl + XPROG_OFF + b * nt + j, j, need, abortp);
+            __syncthreads();
+            const int v = ctl[1];
+            __syncthreads();
+            if (v < 0) return false;
+            availk = min(v, nkt);
+            return true;
+          }
+        };
+        if (!need_kt(min(2, nkt))) return false;
         int pause_seen = 0;
         V16 ra[2], rb[2];
         load_ktile(pj, voff, ra);
@@ -373,7 +411,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           store_ktile(lds + (cur ^ 1) * 2 * OPB, tk, ra);
           store_ktile(lds + (cur ^ 1) * 2 * OPB + OPB, tk, rb);
           const int kn = min(kt + 2, nkt - 1);
-          if (!need_cols((kn >> 3) + 1)) return false;
+          if (!need_kt(kn + 1)) return false;
           if (tid == 0) {                                   // the CU's pause word, read one iteration ahead of its use
             ctl[2 + cur] = pause_seen;
             pause_seen = ld_agent(pausep);
@@ -477,7 +515,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
             // stores of column block CB - 2 have been acknowledged)
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();                                  // image CB is complete (and the poll's result is in)
-            if (CB >= 2 && i == j + 1 && tid == 0) st_agent(xprog, CB - 1);
+            if (CB >= 2 && tid == 0) st_agent(i == j + 1 ? xprog : yprog, CB - 1);
             if constexpr (CB < 7) {
               okc = min(okc, ctl[2 + (CB & 1)]);
               fetch(CB + 1, pv);
@@ -509,7 +547,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           wait_vm0();
           __syncthreads();
           if (tid == 0) {
-            if (i == j + 1) st_agent(xprog, 8);
+            st_agent(i == j + 1 ? xprog : yprog, 8);
             st_agent(ready + i, j + 1);
             if (i == j + 1) st_agent(pausep, 0);
           }
