@@ -251,7 +251,7 @@ def test_potrs_inv_streaming_form(be, N, P):
         dev.solve_alpha("inverse")                               # two tile-GEMM launches
         a_gemm = dev.alpha.clone()
     finally:
-        be.check(be.lib.gpk_set_option(be.h, b"k3_stream_min_np", 8192))
+        be.check(be.lib.gpk_set_option(be.h, b"k3_stream_min_np", 512))
     scale = float(a_chain.abs().max())
     assert bool(torch.isfinite(a_stream).all())
     assert float((a_stream - a_gemm).abs().max()) < 1e-12 * scale

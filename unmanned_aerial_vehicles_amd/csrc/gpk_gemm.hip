@@ -471,7 +471,12 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
     // sched_barrier, s_setprio around the MFMAs: equal or slower on the throughput shapes; 2 or 4 k-tiles per
     // iteration for the 64-tile small-grid configuration: no gain.)
     constexpr int NP = TS * 8 / NT;
-    V16 ra[NP], rb[NP];
+    // The 64-tile configuration runs launches of a few hundred workgroups, one or two per CU: with one k-tile of fetch
+    // distance such a launch is bound by the latency of its fetches (2.7 us per k-tile of 0.5 us of MFMA work measured at
+    // 512 workgroups).  It keeps TWO k-tiles in flight in two register sets (it has the registers: 85 of 128): the set
+    // written to LDS at the top of iteration kt (k-tile kt + 1) is refilled with k-tile kt + 3.
+    constexpr bool DEEP = TS == 64;
+    V16 ra[NP], rb[NP], ra2[NP], rb2[NP];    // (the second set is dead code in the other configurations)
     unsigned offa[NP], offb[NP];
     tile_offsets<T, TA, NT, TS>(p.lda, tid, offa);
     tile_offsets<T, TB, NT, TS>(p.ldb, tid, offb);
@@ -489,19 +494,32 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
       const int k1 = min(1, nkt - 1);
       load_tile<NP>(ua + k1 * sa, offa, ra);
       load_tile<NP>(ub + k1 * sb, offb, rb);
+      if constexpr (DEEP) {
+        const int k2 = min(2, nkt - 1);
+        load_tile<NP>(ua + k2 * sa, offa, ra2);
+        load_tile<NP>(ub + k2 * sb, offb, rb2);
+      }
     }
     __syncthreads();
-    // two k-tiles per trip so that the LDS buffer index is a compile-time constant (immediate offsets on every
-    // ds instruction, no vector address arithmetic in the body)
+    // two k-tiles per trip so that the LDS buffer index (and, with two register sets, the set) is a compile-time constant
+    // (immediate offsets on every ds instruction, no vector address arithmetic in the body)
     auto body = [&](int kt, auto curc) {
       constexpr int cur = decltype(curc)::value;
-      store_tile<T, TA, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
-      store_tile<T, TB, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
-      const int kn = min(kt + 2, nkt - 1);
       const char* la = lds + cur * 2 * LDS_OP_BYTES;
       const char* lb = la + LDS_OP_BYTES;
-      load_tile<NP>(ua + kn * sa, offa, ra);
-      load_tile<NP>(ub + kn * sb, offb, rb);
+      if constexpr (DEEP && cur == 1) {
+        store_tile<T, TA, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra2);
+        store_tile<T, TB, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb2);
+        const int kn = min(kt + 3, nkt - 1);
+        load_tile<NP>(ua + kn * sa, offa, ra2);
+        load_tile<NP>(ub + kn * sb, offb, rb2);
+      } else {
+        store_tile<T, TA, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES, tid, ra);
+        store_tile<T, TB, NT, TS>(lds + (cur ^ 1) * 2 * LDS_OP_BYTES + LDS_OP_BYTES, tid, rb);
+        const int kn = min(kt + (DEEP ? 3 : 2), nkt - 1);
+        load_tile<NP>(ua + kn * sa, offa, ra);
+        load_tile<NP>(ub + kn * sb, offb, rb);
+      }
       compute_tile<TA, TB, AB, NB, TS>(la, lb, row_w, col_w, lane, acc);
       __syncthreads();
     };

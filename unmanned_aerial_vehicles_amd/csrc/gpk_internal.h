@@ -43,7 +43,8 @@ struct gpk_context {
   int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
   int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
   int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
-  int k3_stream_min_np = 8192;   // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6)
+  int k3_stream_min_np = 512;    // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6); measured faster than the two
+                                 // 128-column tile GEMMs from there on (N = 4096: 0.11 against 0.35 ms, profiles/r04_k3_ab.log)
   int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
                              // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
   int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 512 <= Np <= ptile_max_np (GPK_PTILE=0: recursion)
