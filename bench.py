@@ -120,6 +120,74 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
+class BoardSensors:
+    """Board power and shader clock of this process's GPU while the timed steps run: the card's own hwmon files
+    (/sys/class/drm/card*/device/hwmon/hwmon*/power1_input in microwatts, freq1_input in Hz), matched to the device by PCI
+    bus id, sampled every 10 ms by a host thread.  Evidence for `roofline.pmc`: whether the matrix pipe's clock under the
+    variance launch is the power management's doing.  Returns None where the files are not readable."""
+
+    def __init__(self, device_index):
+        import glob
+        self.power = self.freq = self.cap = None
+        self.samples = []
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}."
+        except Exception:                                   # noqa: BLE001
+            want = None
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if want else []:
+            real = os.path.realpath(os.path.join(hw, "..", ".."))
+            if want not in real:
+                continue
+            if os.path.exists(os.path.join(hw, "power1_input")):
+                self.power = os.path.join(hw, "power1_input")
+                self.freq = os.path.join(hw, "freq1_input")
+                self.cap = os.path.join(hw, "power1_cap")
+                self.pci = os.path.basename(real)
+                break
+        self._stop = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:                                   # noqa: BLE001
+            return None
+
+    def start(self):
+        if not self.power:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                p, fq = self._read(self.power), self._read(self.freq)
+                if p is not None:
+                    self.samples.append((p * 1e-6, (fq or 0.0) * 1e-6))
+                self._stop.wait(0.01)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if not self._stop:
+            return None
+        self._stop.set()
+        self._thread.join()
+        if not self.samples:
+            return None
+        pw = np.array([a for a, _ in self.samples])
+        fq = np.array([b for _, b in self.samples])
+        cap = self._read(self.cap)
+        return {"board_power_w_avg": float(pw.mean()), "board_power_w_max": float(pw.max()),
+                "power_cap_w": cap * 1e-6 if cap else None,
+                "sclk_mhz_avg": float(fq.mean()), "sclk_mhz_min": float(fq.min()), "sclk_mhz_max": float(fq.max()),
+                "samples": int(len(pw)), "pci": self.pci,
+                "source": "the card's hwmon power1_input / freq1_input, sampled every 10 ms by a host thread over the timed steps"}
+
+
 def synthetic_problem(N, M, D=9, P=3, qseed=1):
     """SURVEY.md §8(d) deterministic inputs (same generator as oracle.gp_oracle.synthetic_problem)."""
     rng = np.random.default_rng(0)
@@ -707,11 +775,15 @@ def main():
         step()
     sync_all()
     dev.timing(True)                               # restart the event ring: it now covers exactly the timed steps
+    sensors = BoardSensors(be.device.index if be.device.index is not None else 0) if rank == 0 else None
+    if sensors:
+        sensors.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync_all()
     dt = time.perf_counter() - t0
+    board = sensors.stop() if sensors else None
     k5_ms = dev.kernel_times(_lib.GPK_TIMED_K5)    # the dominant launch of every timed step (the last 64 of them)
     dev.timing(False)
     if use_dist:
@@ -824,6 +896,8 @@ def main():
                 # pipe is and the clock the chip holds under it - the product of the two is what `frac_issued` can reach
                 "pmc": ({k: tr[k] for k in ("pmc_mfma_busy", "pmc_clock_ghz", "pmc_l2_hit_rate", "pmc_source") if k in tr}
                         or None) if tr else None,
+                # measured in THIS run: the board's power and shader clock over the timed steps
+                "board": board,
                 "launches_per_step": lps if method != "solve" else 2 * (dev.Np // 128) - 1,
                 "kernel_ms": k5_s * 1e3, "kernel_ms_min_max": [float(np.min(step_ms)), float(np.max(step_ms))],
                 "timed_launches": int(len(k5_ms)), "timed_steps": int(len(step_ms)),
