@@ -383,6 +383,99 @@ def test_trtri_wtw_super_tile_sizes(be, Np):
     assert float(torch.max(torch.abs(Kinv[lower] - ref[lower]))) < 1e-11 * float(torch.max(torch.abs(ref)))
 
 
+def _random_factor(be, Np, seed):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = torch.randn((Np, Np), dtype=torch.float64, generator=g)
+    L = torch.tril(A) * 0.02
+    L.diagonal().copy_(1.0 + torch.rand(Np, dtype=torch.float64, generator=g))
+    Ld = L.to(be.device).contiguous()
+    Ld += torch.triu(torch.full((Np, Np), 7.0, dtype=torch.float64, device=be.device), diagonal=1)
+    return Ld
+
+
+def _trtri_wtw(be, Ld, options):
+    """(W, K^-1) with the given library options set for the duration of the two calls."""
+    import torch
+    Np = Ld.shape[0]
+    defaults = {b"gemm_balanced": 1, b"trtri_levels": 1}
+    winv = be.empty((Np, 128), torch.float64)
+    W = torch.full((Np, Np), float("nan"), dtype=torch.float64, device=be.device)
+    Kinv = torch.zeros((Np, Np), dtype=torch.float64, device=be.device)
+    work = be.empty(((Np // 2 + 128) ** 2,), torch.float64)
+    be.bind_stream()
+    for k, v in options.items():
+        be.check(be.lib.gpk_set_option(be.h, k, v))
+    try:
+        be.check(be.lib.gpk_leaf_inverses(be.h, _p(Ld), Np, Np, _p(winv)))
+        be.check(be.lib.gpk_trtri(be.h, _p(Ld), Np, Np, _p(winv), _p(W), Np, _p(work)))
+        be.check(be.lib.gpk_wtw(be.h, _p(W), Np, Np, _p(Kinv), Np))
+    finally:
+        for k in options:
+            be.check(be.lib.gpk_set_option(be.h, k, defaults[k]))
+    return torch.tril(W), torch.tril(Kinv)
+
+
+@pytest.mark.parametrize("Np", [640, 1152, 2176, 4224])
+def test_balanced_tile_schedule_is_bit_identical(be, Np):
+    """Products with triangular operands (the two level products of gpk_trtri, W^T W) under the balanced persistent tile
+    schedule (gpk_gemm.hip: tiles enumerated longest k-range first, dealt in serpentine order to the resident workgroups)
+    against the static tile mapping: the schedule changes which workgroup computes a tile, never a tile's arithmetic."""
+    import torch
+    Ld = _random_factor(be, Np, Np)
+    Wb, Kb = _trtri_wtw(be, Ld, {b"gemm_balanced": 1})
+    Ws, Ks = _trtri_wtw(be, Ld, {b"gemm_balanced": 0})
+    assert bool(torch.isfinite(Wb).all()) and bool(torch.isfinite(Kb).all())
+    assert torch.equal(Wb, Ws) and torch.equal(Kb, Ks)
+
+
+@pytest.mark.parametrize("nl", [2, 3, 5, 7, 9, 13, 17, 31])
+def test_trtri_level_by_level_any_tile_count(be, nl):
+    """gpk_trtri level by level for tile counts that are not a power of two (a ragged tail block merged per level; the
+    reference trains at N = 10 000 = 79 tiles) against the depth-first recursion and against W L = I."""
+    import torch
+    Np = 128 * nl
+    Ld = _random_factor(be, Np, 1000 + nl)
+    Wl, Kl = _trtri_wtw(be, Ld, {b"trtri_levels": 1})
+    Wr, Kr = _trtri_wtw(be, Ld, {b"trtri_levels": 0})
+    scale = float(Wr.abs().max())
+    assert float((Wl - Wr).abs().max()) < 1e-12 * scale
+    assert float((Kl - Kr).abs().max()) < 1e-12 * float(Kr.abs().max())
+    eye = torch.eye(Np, dtype=torch.float64, device=be.device)
+    assert float(torch.max(torch.abs(Wl @ torch.tril(Ld) - eye))) < 1e-11
+
+
+@pytest.mark.parametrize("B,nl", [(3, 5), (2, 8), (4, 11)])
+def test_trtri_wtw_batched_mode_matches_single(be, B, nl):
+    """In the handle's batched mode (config C5: the per-axis GPs as one launch chain) every level of gpk_trtri is one launch
+    for all problems - explicit GEMM batches inside the handle's batch: each problem's W and K^-1 bit-identical to its own
+    single-problem call."""
+    import torch
+    Np = 128 * nl
+    Ls = [_random_factor(be, Np, 77 * nl + b) for b in range(B)]
+    singles = [_trtri_wtw(be, L, {}) for L in Ls]
+    Ld = torch.stack(Ls).contiguous()
+    winv = be.empty((B, Np, 128), torch.float64)
+    W = torch.full((B, Np, Np), float("nan"), dtype=torch.float64, device=be.device)
+    Kinv = torch.zeros((B, Np, Np), dtype=torch.float64, device=be.device)
+    tsz = (Np // 2 + 128) ** 2
+    work = be.empty((B, tsz), torch.float64)
+    be.bind_stream()
+    for b in range(B):
+        be.check(be.lib.gpk_leaf_inverses(be.h, _p(Ld[b]), Np, Np, _p(winv[b])))
+    be.check(be.lib.gpk_batch_begin(be.h, B))
+    try:
+        for t, row_bytes in ((Ld, Np * Np * 8), (winv, Np * 128 * 8), (W, Np * Np * 8), (Kinv, Np * Np * 8), (work, tsz * 8)):
+            be.check(be.lib.gpk_batch_buffer(be.h, _p(t), row_bytes))
+        be.check(be.lib.gpk_trtri(be.h, _p(Ld), Np, Np, _p(winv), _p(W), Np, _p(work)))
+        be.check(be.lib.gpk_wtw(be.h, _p(W), Np, Np, _p(Kinv), Np))
+    finally:
+        be.lib.gpk_batch_end(be.h)
+    for b in range(B):
+        assert torch.equal(torch.tril(W[b]), singles[b][0])
+        assert torch.equal(torch.tril(Kinv[b]), singles[b][1])
+
+
 @pytest.mark.parametrize("Np", [384, 4096, 4224])
 def test_potri_with_poisoned_work(be, Np):
     """gpk_potri (K6b: K^-1 = (L L^T)^-1 in one call) with `work` and `Kinv` full of NaN on entry: gpk.h documents

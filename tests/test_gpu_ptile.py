@@ -145,3 +145,31 @@ def test_one_launch_repeatable_and_large(be):
     _, _, L0, W0 = potrf(be, A, 0)
     assert np.abs(L - np.tril(L0)).max() < 1e-12 * np.abs(L).max()
     assert np.abs(Wa - W0).max() < 1e-11 * np.abs(W0).max()
+
+
+@pytest.mark.parametrize("n", [640, 1000, 2048, 3000])
+def test_one_launch_handovers_on_and_off(be, n):
+    """The 16-column hand-overs (the two tiles under a diagonal tile follow its factorisation block row by block row -
+    forward substitution with L_jj's rows and the W_bb - and publish their own 16-column blocks) against the same launch
+    with whole-tile hand-overs (ptile_prog_max_nt = 0: the tile under the diagonal multiplies by the finished W_jj):
+    different arithmetic for those tiles, the same factor to rounding; both against LAPACK."""
+    A = spd(n, 31 + n)
+    be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_max_nt", 0))
+    try:
+        rc0, info0, L0, W0 = potrf(be, A, 1)
+    finally:
+        be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_max_nt", 128))
+    rc1, info1, L1, W1 = potrf(be, A, 1)
+    assert rc0 == 0 and rc1 == 0 and info0 == 0 and info1 == 0
+    L0, L1 = np.tril(L0), np.tril(L1)
+    ref = np.linalg.cholesky(A)
+    scale = np.abs(ref).max()
+    assert np.abs(L1 - ref).max() < 1e-12 * scale and np.abs(L0 - ref).max() < 1e-12 * scale
+    assert np.abs(L1 - L0).max() < 1e-12 * scale
+    assert np.abs(W1 - W0).max() < 1e-11 * np.abs(W0).max()
+    be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", 1))
+    try:
+        _, info2, L2, W2 = potrf(be, A, 1)
+    finally:
+        be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", 2))
+    assert info2 == 0 and np.abs(np.tril(L2) - ref).max() < 1e-12 * scale
