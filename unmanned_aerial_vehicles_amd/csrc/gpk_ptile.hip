@@ -61,7 +61,7 @@ constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
 constexpr int YPROG_OFF = XPROG_OFF + 8 * 512; // ctrl ints: per tile row i, likewise for tile (i, i - 2)
 constexpr int XS = 18;                        // row stride (doubles) of a wave's 16 x 16 output staging block
-static_assert((18 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: two images and the waves' staging blocks");
+static_assert((22 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: two L images, the waves' W blocks and staging blocks");
 
 static_assert(4 * OPB <= CTL_OFF, "staging buffers");
 static_assert(36 * BLK * 8 <= CTL_OFF, "W_jj image");
@@ -460,9 +460,8 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           // ---- the tile below the diagonal is the critical path: it does not wait for W_jj.  X L_jj^T = X^ by forward
           //      substitution, one 16-column step behind the diagonal task's factorisation:
           //          X_c^T = W_cc (X^_c^T - sum_{k<c} L(c, k) X_k^T)
-          //      needs block row c of L_jj and the diagonal block W_cc only - both final (and published: wprog) one step after
-          //      the diagonal task has formed them - and runs in place in ascending order; when the diagonal task is done,
-          //      the last block row is all that is left.  Two LDS images (block row c + 1 is fetched under step c's products).
+          //      needs block row c of L_jj and the diagonal block W_cc only and runs in place in ascending order; when the
+          //      diagonal task is done, one fetch of W_77 and one block product are left.
           // (the tile below that one does the same: the next column's critical tile needs it for its last k-step, and with
           // the whole of W_jj it would be final some 15 us later)
           if (i == j + 1 && tid == 0) st_agent(pausep, j + 1);   // critical from here to its publication
@@ -470,68 +469,74 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           const double* Wjj = Wv + (long long)j * TS * TS;
           const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ljj), 0, 0x7fffffff, 0x00020000);
           const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Wjj), 0, 0x7fffffff, 0x00020000);
-          // block row c: blocks 0 .. c - 1 are L(c, k), block c is W_cc.  Wave w brings in block w (two 16-byte pieces per
-          // lane); an aborted launch is noticed once, after the steps (whatever they read meanwhile is valid memory).
-          auto fetch = [&](int c, V16 (&v)[2]) {
-            if (wave <= c) {
+          // Block row c of the substitution: the blocks L(c, k), k < c - final one step BEFORE W_cc (the diagonal task stores
+          // L(c, k) in its step k) and published with the same word: wprog >= c - and the diagonal block W_cc (wprog >= c + 1).
+          // Wave w brings in L(c, w) (two 16-byte pieces per lane, negated on the way into the image the step after next reads);
+          // EVERY wave brings in its own copy of W_cc (2 KiB: no barrier between the fetch and the one product that needs it).
+          // With the update part of step c done under the fetch of W_cc, what is left when the diagonal task is done is one
+          // fetch and one block product.  An aborted launch is noticed once, after the steps (whatever they read meanwhile is
+          // valid memory).
+          auto fetchL = [&](int c, V16 (&v)[2]) {
+            if (wave < c) {
               const int ln = fresh_tid() & 63, prow = ln >> 2, pcol = 4 * (ln & 3);   // pieces (prow, pcol) and (prow, pcol + 2)
-              const bool isw = wave == c;
-              const __amdgpu_buffer_rsrc_t rs = isw ? rw_ : rl;
-              const long long ld = isw ? (long long)TS : lda;
-              const unsigned off = (unsigned)(((long long)(16 * c + prow) * ld + 16 * wave + pcol) * 8);
-              v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
-              v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 16);
+              const unsigned off = (unsigned)(((long long)(16 * c + prow) * lda + 16 * wave + pcol) * 8);
+              v[0] = __builtin_amdgcn_raw_buffer_load_b128(rl, off, 0, 16);
+              v[1] = __builtin_amdgcn_raw_buffer_load_b128(rl, off + 16, 0, 16);
             }
           };
-          auto put = [&](int c, double* img, const V16 (&v)[2]) {
-            if (wave <= c) {
+          auto putL = [&](int c, double* img, const V16 (&v)[2]) {
+            if (wave < c) {
               const int ln = fresh_tid() & 63, prow = ln >> 2, pcol = 4 * (ln & 3);
-              const double sg = wave == c ? 1.0 : -1.0;
               double* dstp = img + wave * BLK + prow * BS + pcol;
   #pragma unroll
               for (int u = 0; u < 2; ++u) {
                 const dv2 d = __builtin_bit_cast(dv2, v[u]);
-                dstp[2 * u] = sg * d.x;
-                dstp[2 * u + 1] = sg * d.y;
+                dstp[2 * u] = -d.x;
+                dstp[2 * u + 1] = -d.y;
               }
             }
           };
+          auto fetchW = [&](int c, V16 (&v)[2]) {
+            const int ln = fresh_tid() & 63, prow = ln >> 2, pcol = 4 * (ln & 3);
+            const unsigned off = (unsigned)(((16 * c + prow) * TS + 16 * c + pcol) * 8);
+            v[0] = __builtin_amdgcn_raw_buffer_load_b128(rw_, off, 0, 16);
+            v[1] = __builtin_amdgcn_raw_buffer_load_b128(rw_, off + 16, 0, 16);
+          };
+          double* wmine = wl + (14 + wave) * BLK;              // this wave's copy of the current W_cc
+          auto putW = [&](const V16 (&v)[2]) {
+            const int ln = fresh_tid() & 63, prow = ln >> 2, pcol = 4 * (ln & 3);
+  #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const dv2 d = __builtin_bit_cast(dv2, v[u]);
+              wmine[prow * BS + pcol + 2 * u] = d.x;
+              wmine[prow * BS + pcol + 2 * u + 1] = d.y;
+            }
+          };
           const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(Atile, 0, 0x7fffffff, 0x00020000);
-          V16 pv[2] = {};
+          V16 pl[2] = {}, pw[2] = {};
           int okc = 0;                                        // < 0: the launch was aborted while a poll was waiting
           if (tid == 0) ctl[1] = poll_ready(wprog, nullptr, 1, abortp);
           __syncthreads();
           okc = min(okc, ctl[1]);
           PT_STAMP(2);
-          fetch(0, pv);
+          fetchW(0, pw);
+          fetchL(1, pl);
           sfor<0, 8>([&](auto cc) {
             constexpr int CB = decltype(cc)::value;
-            double* img = wl + (CB & 1) * 9 * BLK;
-            put(CB, img, pv);
-            if constexpr (CB < 7) {                           // the next block row: wait for it, then fetch it under this step's products
-              if (tid == 0) ctl[2 + (CB & 1)] = poll_ready(wprog, nullptr, CB + 2, abortp);
-            }
-            // (vector memory operations complete in order: with at most the two stores of step CB - 1 outstanding, this wave's
-            // stores of column block CB - 2 have been acknowledged)
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            __syncthreads();                                  // image CB is complete (and the poll's result is in)
-            if (CB >= 2 && tid == 0) st_agent(i == j + 1 ? xprog : yprog, CB - 1);
-            if constexpr (CB < 7) {
-              okc = min(okc, ctl[2 + (CB & 1)]);
-              fetch(CB + 1, pv);
-            }
-            if constexpr (CB == 7) PT_STAMP(3);
+            const double* img = wl + (CB & 1) * 7 * BLK;      // L(CB, 0 .. CB - 1), negated: in LDS since the previous step's barrier
             const int tq = fresh_tid(), qr = tq & 15, qq = (tq >> 4) & 3;      // (per step: nothing to keep alive across steps)
+            if constexpr (CB == 7) PT_STAMP(3);
             d4 acc = S[CB];
             sfor<0, CB>([&](auto kc) {
               constexpr int KB = decltype(kc)::value;
               acc = blk_mfma<false>(img + KB * BLK, S[KB], acc, qr, qq);
             });
-            S[CB] = blk_mfma<false>(img + CB * BLK, acc, d4{0.0, 0.0, 0.0, 0.0}, qr, qq);
+            putW(pw);                                         // (same-wave LDS traffic is ordered: no barrier)
+            S[CB] = blk_mfma<false>(wmine, acc, d4{0.0, 0.0, 0.0, 0.0}, qr, qq);
             // ---- column block CB of the tile is final: out it goes (this wave's 16 rows x 16 columns through the wave's own
             //      staging block, two 16-byte write-through stores per lane) - the next diagonal task takes it as one k-tile
             {
-              double* stg = wl + 18 * BLK + wave * (16 * XS);
+              double* stg = wl + 22 * BLK + wave * (16 * XS);
   #pragma unroll
               for (int t = 0; t < 4; ++t) stg[qr * XS + qq + 4 * t] = S[CB][t];
               const int ln = tq & 63, prow = ln >> 2, pcol = 4 * (ln & 3);
@@ -540,6 +545,19 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
                 const V16 v = *reinterpret_cast<const V16*>(stg + prow * XS + pcol + 2 * u);
                 __builtin_amdgcn_raw_buffer_store_b128(v, rx, (unsigned)(((long long)(16 * wave + prow) * lda + 16 * CB + pcol + 2 * u) * 8), 0, 16);
               }
+            }
+            if constexpr (CB < 7) {
+              // ---- the next step: its L blocks go into the other image, then wait for W_(CB+1) (and with it L row CB + 2)
+              putL(CB + 1, wl + ((CB + 1) & 1) * 7 * BLK, pl);
+              if (tid == 0) ctl[2 + (CB & 1)] = poll_ready(wprog, nullptr, CB + 2, abortp);
+              // (vector memory operations complete in order: with this step's two stores the only ones outstanding, this
+              // wave's stores of column block CB - 1 have been acknowledged)
+              asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+              __syncthreads();                                // image CB + 1 is complete, the poll's result is in
+              if (CB >= 1 && tid == 0) st_agent(i == j + 1 ? xprog : yprog, CB);
+              okc = min(okc, ctl[2 + (CB & 1)]);
+              fetchW(CB + 1, pw);
+              if constexpr (CB < 6) fetchL(CB + 2, pl);
             }
           });
           if (okc < 0) return false;
@@ -701,7 +719,15 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
             __builtin_amdgcn_sched_barrier(0);
           });
         }
+        // (the last step publishes the previous step's block row already here, a phase early: its stores are a whole sweep old,
+        // and the tile under this one then has nothing but W_77 left to fetch when this task is done)
+        if constexpr (JB == 7) {
+          if (p.prog) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
+        if constexpr (JB == 7) {
+          if (p.prog && tid == 0) st_agent(wprog, 7);
+        }
         PT_STAMP(2 + JB);
         // ---- phase B: S[JB] <- W_bb * S[JB]: below the diagonal block that is L(rw, JB)^T, in the columns of the inverse
         //      W(JB, rw); the wave of the diagonal block itself takes W_bb as it stands
