@@ -74,8 +74,12 @@ GPK_API int64_t gpk_padded(int64_t n);
  * "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = the tallest of the 512 / 256 / 128 x 128 tiles that still comes in at
  * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256",
  * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
- * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain).  Used by the A/B timings and by the tests that pin a fast path
- * to its plain form.                                                                                                */
+ * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
+ * up to this many tile columns (128 = always) the tiles under a diagonal tile follow its factorisation 16 columns at a time,
+ * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 or 2 such tiles per column), "gemm_balanced" (tile GEMMs whose
+ * tiles differ in k-range - the products with triangular operands of gpk_trtri / gpk_wtw / gpk_potrs_inv: 1 = the balanced
+ * persistent tile schedule, 0 = the static tile mapping; bit-identical results), "gemm_balanced_max_tiles".  Used by the A/B
+ * timings and by the tests that pin a fast path to its plain form.                                                   */
 GPK_API int gpk_set_option(gpk_handle h, const char* name, int value);
 enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2, GPK_TIMED_GRAD = 3, GPK_TIMED_POTRF = 4 };
 GPK_API int gpk_timing(gpk_handle h, int enable);

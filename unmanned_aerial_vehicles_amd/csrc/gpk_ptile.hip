@@ -34,6 +34,18 @@
 // hold a stale copy.  L_jj (nobody reads it inside the launch) uses plain stores.
 // Every spin loop gives up after GPK_PTILE_TIMEOUT_TICKS of the 100 MHz real-time counter and raises an abort word that
 // every other loop polls: the grid always drains.
+//
+// The hand-overs along the diagonal run 16 columns at a time (p.prog): the critical path is
+//   D(j) -> T(j+1, j) -> last k-step of D(j+1) -> D(j+1),
+// and each arrow through whole tiles costs a write-through acknowledgement, a flag and 64-128 KB of freshly written lines.
+// Instead the diagonal task publishes "block rows < v of L_jj and their 16 x 16 inverses W_bb are final" as it goes
+// (wprog; its waves count their own stores - vector memory operations complete in order - so the acknowledgement wait is
+// taken one or two steps late and does not stall); the tasks of the two tiles under it (a third instantiation of the task
+// body, PROG) solve  X L_jj^T = X^  by forward substitution behind it, block row by block row, and publish every finished
+// 16-column block of their own tile (xprog / yprog); and whoever multiplies those tiles next takes them k-tile by k-tile
+// (poll_ktiles).  When a diagonal task is done, the tile under it has one fetch and one block product left, and when that
+// tile is done the next diagonal task has one k-tile left.  Deadlock freedom is unchanged: every wait is still for a task
+// earlier in the list.
 #include <cstdlib>
 
 #include "gpk_internal.h"
