@@ -50,6 +50,7 @@
 
 #include "gpk_internal.h"
 #include "gpk_p2.h"
+#include "gpk_p4.h"
 
 namespace {
 
@@ -692,10 +693,6 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         constexpr int KB = decltype(kc)::value;
         if (KB > rw) S[KB] = d4{0.0, 0.0, 0.0, 0.0};
       });
-      if (rw == 0) {
-  #pragma unroll
-        for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[0][t];
-      }
       __syncthreads();
       sfor<0, 8>([&](auto jc) {
         constexpr int JB = decltype(jc)::value;
@@ -703,7 +700,13 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         // ---- phase A: one wave factors the diagonal block; the others apply block column C = JB - 1:
         //      S[X] -= L(X, C) * S[C] for X = C + 1 .. rw (factor rows) or C + 1 .. 7 (inverse columns, rw <= C)
         if (rw == JB) {
-          const int bad = gpk_p2_factor(dblk, BS, lc + JB * BLK, BS, wd + JB * BLK, BS, lane, S);
+          d4 ub = S[JB], xb;                                          // the block itself, as this wave holds it
+          const int bad = gpk_p4_factor(ub, xb, lane);
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            wd[JB * BLK + lr * BS + lq + 4 * t] = xb[t];              // wd[b][r][c] = W_bb[c][r]
+            lc[JB * BLK + lr * BS + lq + 4 * t] = ub[t];              // L_bb, row-major (for its store below)
+          }
           if (bad != 0 && lane == 0) atomicCAS(info, 0, p.row0 + TS * j + 16 * JB + bad);
   #pragma unroll
           for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
@@ -760,8 +763,6 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   #pragma unroll
               for (int t = 0; t < 4; ++t)
                 S[JB + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[JB][t], -S[JB][t], S[JB + 1], 0, 0, 0);
-  #pragma unroll
-              for (int t = 0; t < 4; ++t) dblk[lr * BS + lq + 4 * t] = S[JB + 1][t];
             }
           }
           // (write-through, as W below: the task of the tile under this one reads L_jj and the W_bb block row by block row
