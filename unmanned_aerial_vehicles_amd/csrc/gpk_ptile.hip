@@ -22,7 +22,8 @@
 //     so X^T = W_jj X^^T runs straight from the accumulators (A = blocks of W_jj from LDS), in place.
 //   * the diagonal task keeps the lower triangle the same way (wave = one block row r: blocks (r, 0 .. r) transposed,
 //     later the blocks of column r of the inverse) and factors it right-looking: the 16 x 16 diagonal block and its
-//     inverse by ONE wave in registers (gpk_p2.h), the blocks below it by W_bb * (accumulator), the trailing update and
+//     inverse by ONE wave on that accumulator itself (gpk_p4.h: four panel steps of 4 x 4 closed forms on wave-uniform
+//     scalars and rank-4 MFMA updates), the blocks below it by W_bb * (accumulator), the trailing update and
 //     the forward substitution for the inverse by L_(i, b) (one block column of L in LDS) * (accumulator).  While one
 //     wave works on a diagonal block the other seven apply the previous block column.
 //
@@ -49,7 +50,6 @@
 #include <cstdlib>
 
 #include "gpk_internal.h"
-#include "gpk_p2.h"
 #include "gpk_p4.h"
 
 namespace {
@@ -79,7 +79,7 @@ static_assert((22 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: tw
 static_assert(4 * OPB <= CTL_OFF, "staging buffers");
 static_assert(36 * BLK * 8 <= CTL_OFF, "W_jj image");
 static_assert(TS * OS * 8 <= CTL_OFF, "output staging image");
-static_assert((1 + 8 + 16) * BLK * 8 <= CTL_OFF, "leaf work area");
+static_assert((8 + 16) * BLK * 8 <= CTL_OFF, "leaf work area");
 
 struct PTParams {
   double* A; long long lda; long long strideA;     // strides between the problems of a batch, in bytes
@@ -683,8 +683,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
       // substitution for the inverse (R = -sum L W, then W(k, rw)).  Slot rw changes hands when the wave's own diagonal
       // block has gone to the factoring wave.
       const int tl = fresh_tid(), lane = tl & 63, lr = tl & 15, lq = (tl >> 4) & 3;
-      double* dblk = reinterpret_cast<double*>(lds);                // the current diagonal block, row-major
-      double* wd = dblk + BLK;                                      // wd[b][r][c] = W_bb[c][r]
+      double* wd = reinterpret_cast<double*>(lds);                  // wd[b][r][c] = W_bb[c][r]
       double* lcol = wd + 8 * BLK;                                  // two block columns of L: lcol[buf][block row]
       double* Wj = Wv + (long long)j * TS * TS;
       int* info = p.info + b;
@@ -788,9 +787,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         // write-through stores of the first steps take 6-7 us to be acknowledged while the previous column's tiles are
         // being published, and the wait stalled the factorisation by 3 us in each of its steps 1 and 2.)  From step 4 on,
         // one step late: the task below is left with the last block row only when this one is done.
-        // (Only in launches bound by this chain, p.prog: with the whole chip streaming tiles the acknowledgements take
-        // several steps, and a diagonal task that waits for them eight times per tile instead of once is what the launch
-        // then waits for - N = 16 384 measured 40 ms against 26 ms.)
+        // (p.prog = 0: a launch without the 16-column hand-overs - the A/B switch ptile_prog_max_nt.)
         if (p.prog) {
           if constexpr (JB < 4) {
             if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
