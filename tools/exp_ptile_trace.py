@@ -34,6 +34,14 @@ def main():
         be.check(be.lib.gpk_potrf(be.h, p(K), n, ld, p(winv), C.byref(info)))
     os.environ.pop("GPK_PTILE_TRACE", None)
     t = np.loadtxt(path)
+    sub = t[-4:].ravel()
+    if sub[0] > 0:      # a library built with -DGPK_PTILE_SUBSTAMPS=<step>: one 16-column step of D(2) in shader cycles
+        names = {0: "factoring wave: step start", 1: "block factored and inverted", 2: "W_bb, L_bb in LDS", 3: "barrier 1 passed", 4: "its stores issued",
+                 8: "next row's wave: barrier 1 passed", 9: "L(b+1, b) = W_bb x block", 10: "diagonal block updated, stores issued", 11: "acknowledgement wait over", 12: "barrier 2 passed"}
+        print("sub-steps of D(2), one 16-column step (shader cycles from the factoring wave's step start):")
+        for k in sorted(names):
+            if sub[k] > 0:
+                print(f"   {names[k]:40s} {sub[k] - sub[0]:8.0f}")
     t = t[:-4]
     nt = n // 128
     t0 = t[:, 0].min()

@@ -202,6 +202,11 @@ __device__ __forceinline__ d4 blk_mfma(const double* ablk, const d4& b, d4 acc, 
   return acc;
 }
 
+#ifdef GPK_PTILE_SUBSTAMPS   // (variant build for tools/exp_ptile_trace.py: shader-clock stamps inside step GPK_PTILE_SUBSTAMPS of D(2))
+#define PT_SUB(k) do { if (p.trace && j == 2 && JB == GPK_PTILE_SUBSTAMPS && (tl & 63) == 0) p.trace[(long long)p.ntasks * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PT_SUB(k) do { } while (0)
+#endif
 #define PT_STAMP(k) do { if (p.trace && tid == 0) p.trace[(long long)task * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
@@ -698,15 +703,21 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         double* lc = lcol + (JB & 1) * 8 * BLK;                     // block column JB of L
         // ---- phase A: one wave factors the diagonal block; the others apply block column C = JB - 1:
         //      S[X] -= L(X, C) * S[C] for X = C + 1 .. rw (factor rows) or C + 1 .. 7 (inverse columns, rw <= C)
+        d4 lbb = {0.0, 0.0, 0.0, 0.0};
+        // (the factoring wave shares its SIMD - matrix pipe included - with the wave of block row 7 - JB, which has up to seven
+        // block products to apply meanwhile: the factoring wave goes first)
+        if (rw == JB) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(2);
         if (rw == JB) {
           d4 ub = S[JB], xb;                                          // the block itself, as this wave holds it
+          PT_SUB(0);
           const int bad = gpk_p4_factor(ub, xb, lane);
+          PT_SUB(1);
   #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            wd[JB * BLK + lr * BS + lq + 4 * t] = xb[t];              // wd[b][r][c] = W_bb[c][r]
-            lc[JB * BLK + lr * BS + lq + 4 * t] = ub[t];              // L_bb, row-major (for its store below)
-          }
+          for (int t = 0; t < 4; ++t) wd[JB * BLK + lr * BS + lq + 4 * t] = xb[t];   // wd[b][r][c] = W_bb[c][r]
+          lbb = ub;                                                 // (stored after the barrier: nobody here waits for it)
           if (bad != 0 && lane == 0) atomicCAS(info, 0, p.row0 + TS * j + 16 * JB + bad);
+          PT_SUB(2);
   #pragma unroll
           for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
         } else if constexpr (JB > 0) {
@@ -743,6 +754,8 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           if (p.prog && tid == 0) st_agent(wprog, 7);
         }
         PT_STAMP(2 + JB);
+        if (rw == JB) PT_SUB(3);
+        if (rw == JB + 1) PT_SUB(8);
         // ---- phase B: S[JB] <- W_bb * S[JB]: below the diagonal block that is L(rw, JB)^T, in the columns of the inverse
         //      W(JB, rw); the wave of the diagonal block itself takes W_bb as it stands
         if (rw == JB) {
@@ -751,6 +764,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         } else {
           S[JB] = blk_mfma<true>(wd + JB * BLK, S[JB], d4{0.0, 0.0, 0.0, 0.0}, lr, lq);
         }
+        if (rw == JB + 1) PT_SUB(9);
         if (rw > JB) {
   #pragma unroll
           for (int t = 0; t < 4; ++t) lc[rw * BLK + lr * BS + lq + 4 * t] = S[JB][t];
@@ -774,34 +788,30 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   #pragma unroll
           for (int t = 0; t < 4; ++t)
             __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (rw == JB && lane < 16) {                              // L_bb: lower triangle only (the tile's upper part stays)
-            double* dl = Atile + (long long)(16 * JB + lane) * lda + 16 * JB;
+          if (rw == JB) {                                           // L_bb: lower triangle only (the tile's upper part stays)
+            double* dl = Atile + (long long)(16 * JB + lr) * lda + 16 * JB + lq;
   #pragma unroll
-            for (int c = 0; c < 16; ++c)
-              if (c <= lane) __hip_atomic_store(dl + c, lc[JB * BLK + lane * BS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int t = 0; t < 4; ++t)
+              if (lq + 4 * t <= lr) __hip_atomic_store(dl + 4 * t, lbb[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        // Progress for the tile below.  Steps 0 - 3, two steps late: every wave has seen its stores of step JB - 2 complete (at
-        // most this step's and the previous one's - 4 each, 20 for the wave of the diagonal block - are outstanding), then the
-        // barrier, then one lane publishes "block rows < JB - 1 are final".  (One step late there was measured: the
-        // write-through stores of the first steps take 6-7 us to be acknowledged while the previous column's tiles are
-        // being published, and the wait stalled the factorisation by 3 us in each of its steps 1 and 2.)  From step 4 on,
-        // one step late: the task below is left with the last block row only when this one is done.
+        if (rw == JB + 1) PT_SUB(10);
+        if (rw == JB) PT_SUB(4);
+        // Progress for the tile below, two steps late: every wave has seen its stores of step JB - 2 complete (at most this
+        // step's and the previous one's - 4 each, 8 for the wave of the diagonal block - are outstanding: vector memory
+        // operations complete in order), then the barrier, then one lane publishes "block rows < JB - 1 are final".  (One
+        // step late was measured: the write-through stores take longer than a step to be acknowledged - 6-7 us in the first
+        // steps, while the previous column's tiles are being published - and the wait stalled every step by 800 cycles or
+        // more.)  The last step publishes a phase early instead (above), and the end of the task everything.
         // (p.prog = 0: a launch without the 16-column hand-overs - the A/B switch ptile_prog_max_nt.)
         if (p.prog) {
-          if constexpr (JB < 4) {
-            if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          } else {
-            if (rw == JB) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          }
+          if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
+        if (rw == JB + 1) PT_SUB(11);
         __syncthreads();
-        if (p.prog && tid == 0) {
-          if (JB >= 4) st_agent(wprog, JB);
-          else if (JB >= 2) st_agent(wprog, JB - 1);
-        }
+        if (rw == JB + 1) PT_SUB(12);
+        if (p.prog && JB >= 2 && tid == 0) st_agent(wprog, JB - 1);
       });
       wait_vm0();
       __syncthreads();
