@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Race hunt for the one-launch Cholesky's device-side protocol (ticket order, progress words, 16-column hand-overs): the same
+factorisation REPS times per shape - single problems and batches - every result bit-identical to the first and the launch never
+aborted; buffers poisoned with NaN before every run.    python tools/stress_ptile.py [REPS]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    from unmanned_aerial_vehicles_amd.device import get_backend
+    be = get_backend(0)
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    p = lambda t: C.c_void_p(t.data_ptr())
+    bad = 0
+    t0 = time.time()
+    for n, B in ((640, 1), (1024, 1), (1152, 3), (2048, 1), (2176, 2), (4096, 1), (4096, 3), (8192, 1), (1024, 8)):
+        rng = np.random.default_rng(n + B)
+        X = torch.as_tensor(rng.standard_normal((n, 7)), device=be.device)
+        K0 = be.empty((B, n, n), torch.float64)
+        for b in range(B):
+            ls = np.full(7, 1.5 + 0.3 * b)
+            be.check(be.lib.gpk_gram(be.h, _lib.GPK_F64, p(X), n, 7, ls.ctypes.data_as(_lib._dp), 1.0, 0.05 + 0.01 * b, p(K0[b]), n))
+        ref = None
+        for r in range(reps):
+            K = K0.clone()
+            winv = torch.full((B, n, 128), float("nan"), dtype=torch.float64, device=be.device)
+            info = (C.c_int * 8)()
+            if B > 1:
+                be.check(be.lib.gpk_batch_begin(be.h, B))
+                be.check(be.lib.gpk_batch_buffer(be.h, p(K), n * n * 8))
+                be.check(be.lib.gpk_batch_buffer(be.h, p(winv), n * 128 * 8))
+            try:
+                be.check(be.lib.gpk_potrf(be.h, p(K), n, n, p(winv), info))
+            finally:
+                if B > 1:
+                    be.lib.gpk_batch_end(be.h)
+            L = torch.tril(K)
+            if ref is None:
+                ref = (L.clone(), winv.clone())
+                assert bool(torch.isfinite(L).all()) and bool(torch.isfinite(winv).all())
+            elif not (torch.equal(L, ref[0]) and torch.equal(winv, ref[1])):
+                bad += 1
+                print(f"MISMATCH N={n} B={B} run {r}: |dL| {float((L - ref[0]).abs().max()):.3e}", flush=True)
+        print(f"N={n:5d} B={B}: {reps} runs bit-identical" if bad == 0 else f"N={n} B={B}: {bad} mismatches so far", flush=True)
+    print(f"{'OK' if bad == 0 else 'FAILED'}: {bad} mismatches, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
