@@ -345,6 +345,18 @@ GPK_API int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const 
                  double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
                  double* grad);
 
+/* ---- one optimiser evaluation as one chain ------------------------------------------------------------------------
+ * gpk_lml_eval: K1 (Gram of X with ls, sf2, diag_add = noise + jitter, into K), K2 (factor in place, winv), W = L^-1 (work:
+ * the scratch of gpk_trtri), alpha = W^T (W Yn), the terms of gpk_lml_terms and - grad != NULL - K^-1 = W^T W (Kinv) and the
+ * gradient of gpk_lml_grad: the same launches as the call-by-call route, queued back to back with ONE synchronisation
+ * (call by call there are three: the pivot check, the terms, the gradient).  Device pointers except ls, terms[1 + P],
+ * grad[D + 2], info (host).  Returns GPK_NOT_PD with *info as gpk_potrf (terms / grad then hold nothing).  Np = gpk_padded(N).
+ * Replaces: one call of log_marginal_likelihood(theta, eval_gradient=True), sklearn/gaussian_process/_gpr.py:537-652, as the
+ * optimiser of GaussianProcessRegressor.fit makes it (src/px4/simple_gp.py:167-177).                                      */
+GPK_API int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, double diag_add,
+                 double noise, const double* Yn, int P, double* K, int64_t Np, double* winv, double* W, double* work,
+                 double* alpha, double* Kinv, double* terms, double* grad, int* info);
+
 /* ---- composite calls: a whole model behind the handle ------------------------------------------------------
  * For callers that are not Python: the sequencing the Python host side (device.py, gpr.py) otherwise provides,
  * as thin C++ over the building blocks above.  HOST pointers in and out; the device buffers (X, normalised

@@ -616,3 +616,31 @@ def test_lml_gradient_kernels(be, csv_data, ka):
     dev.solve_alpha()
     g = dev.lml_grad(0.05)
     assert relerr(g[:10], ka["ka6b_grad"]) < 1e-8
+
+
+@pytest.mark.parametrize("N,P,ard", [(1000, 3, False), (700, 1, True), (130, 6, False)])
+def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
+    """gpk_lml_eval - the optimiser's evaluation as one chain of launches with one synchronisation - against the same
+    building blocks called one by one (three synchronisations): the same kernels in the same order, so the terms, the
+    gradient, alpha and the factor are bit-identical; value only (no K^-1) as well; a non-positive-definite trial matrix
+    raises as gpk_potrf does (sklearn/_gpr.py:586-589 turns that into -inf)."""
+    import torch
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, NotPositiveDefinite
+    X, Y = csv_data["X10"][:N, :9], csv_data["Y6"][:N, :P]
+    Yn = (Y - Y.mean(0)) / Y.std(0)
+    ls = 0.5 * (1.0 + 0.1 * np.arange(9)) if ard else 0.5
+    a = DeviceGP(X, Yn, be)
+    a.factorize(ls, 1.3, 0.1001)
+    a.solve_alpha()
+    ld_a, quad_a = a.lml_terms()
+    g_a = a.lml_grad(0.1)
+    b = DeviceGP(X, Yn, be)
+    ld_b, quad_b, g_b = b.lml_eval(ls, 1.3, 0.1001, 0.1, True)
+    assert ld_a == ld_b and np.array_equal(quad_a, quad_b) and np.array_equal(g_a, g_b)
+    assert torch.equal(a.alpha, b.alpha) and torch.equal(torch.tril(a.K), torch.tril(b.K))
+    c = DeviceGP(X, Yn, be)
+    ld_c, quad_c, g_c = c.lml_eval(ls, 1.3, 0.1001, 0.1, False)
+    assert g_c is None and ld_c == ld_a and np.array_equal(quad_c, quad_a)
+    with pytest.raises(NotPositiveDefinite):
+        b.lml_eval(ls, 1.3, -5.0, 0.1, True)
+    assert not b.factored

@@ -81,6 +81,8 @@ SIGNATURES = {
     "gpk_lml_terms": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _int, _dp]),
     "gpk_potri": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "gpk_lml_grad": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _int, _vp, _i64, _dp]),
+    "gpk_lml_eval": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _dbl, _dbl, _vp, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _dp, _dp,
+                            C.POINTER(C.c_int)]),
     "gpk_gemm_tiles": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _dbl,
                               _dbl, _int]),
 }

@@ -716,24 +716,25 @@ int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const d
 
 }  // namespace
 
-extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int* info) {
-  if (!h) return GPK_BAD_ARG;
-  GPK_REQUIRE(h, A && winv && info, "potrf: null pointer");
+// The launches of gpk_potrf without its synchronisation (gpk_lml_eval queues the rest of an evaluation behind them);
+// gpk_potrf_finish reads the pivot failures back once the stream has been synchronised.
+int gpk_potrf_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv) {
+  GPK_REQUIRE(h, A && winv, "potrf: null pointer");
   GPK_REQUIRE(h, Np >= NB && Np % NB == 0 && lda >= Np && lda % 2 == 0, "potrf: Np must be a positive multiple of 128");
   GPK_REQUIRE(h, Np < (1ll << 31), "potrf: Np too large");
   GPK_REQUIRE(h, ((uintptr_t)A % 16) == 0 && ((uintptr_t)winv % 16) == 0, "potrf: A, winv must be 16-byte aligned");
-  const int nb = h->batch;                         // batched mode: info receives one entry per problem
-  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, nb * sizeof(int), h->stream));
+  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, h->batch * sizeof(int), h->stream));
   gpk_time_begin(h, GPK_TIMED_POTRF);
   h->ptile_launches = 0;
   const int rc = potrf_rec(h, A, lda, Np, winv, 0);
   gpk_time_end(h);
-  GPK_TRY(rc);
-  const int one_launch = h->ptile_launches > 0;
-  int hinfo_all[GPK_MAX_BATCH] = {0};
-  GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo_all, h->d_info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-  if (one_launch) GPK_TRY(gpk_potrf_ptile_check(h));
+  return rc;
+}
+
+// after the stream has been synchronised and d_info copied to hinfo_all (one entry per problem of the batch)
+int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info) {
+  const int nb = h->batch;
+  if (h->ptile_launches > 0) GPK_TRY(gpk_potrf_ptile_check(h));
   int hinfo = 0;
   for (int b = 0; b < nb; ++b) {
     info[b] = hinfo_all[b];
@@ -746,6 +747,16 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, doubl
     return GPK_NOT_PD;
   }
   return GPK_OK;
+}
+
+extern "C" int gpk_potrf(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int* info) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, info, "potrf: null pointer");
+  GPK_TRY(gpk_potrf_enqueue(h, A, Np, lda, winv));
+  int hinfo_all[GPK_MAX_BATCH] = {0};                // batched mode: info receives one entry per problem
+  GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo_all, h->d_info, h->batch * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  return gpk_potrf_finish(h, hinfo_all, info);
 }
 
 extern "C" int gpk_leaf_inverses(gpk_handle h, const double* L, int64_t Np, int64_t ldl, double* winv) {
@@ -808,14 +819,22 @@ extern "C" int gpk_trsm_lower_left(gpk_handle h, int dtype, const void* L, int64
   return trsm_left_rec<float>(h, (float*)B, ldb, Mp, (const float*)L, ldl, Np, (const float*)winv);
 }
 
+// the launch of gpk_lml_terms: 1 + P doubles to dout (device)
+int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
+                          double* dout) {
+  GPK_REQUIRE(h, L && Y && alpha, "lml_terms: null pointer");
+  GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P && N >= 1, "lml_terms: bad sizes");
+  hipLaunchKernelGGL(lml_terms_kernel, dim3(1 + P), dim3(256), 0, h->stream, L, (long long)N, (long long)ldl, Y,
+                     alpha, P, dout);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
 extern "C" int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y,
                              const double* alpha, int P, double* terms) {
   if (!h) return GPK_BAD_ARG;
-  GPK_REQUIRE(h, L && Y && alpha && terms, "lml_terms: null pointer");
-  GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P && N >= 1, "lml_terms: bad sizes");
-  hipLaunchKernelGGL(lml_terms_kernel, dim3(1 + P), dim3(256), 0, h->stream, L, (long long)N, (long long)ldl, Y,
-                     alpha, P, h->d_small);
-  GPK_LAUNCH_CHECK(h);
+  GPK_REQUIRE(h, terms, "lml_terms: null pointer");
+  GPK_TRY(gpk_lml_terms_enqueue(h, L, N, ldl, Y, alpha, P, h->d_small));
   GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, (1 + P) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < 1 + P; ++i) terms[i] = h->h_small[i];

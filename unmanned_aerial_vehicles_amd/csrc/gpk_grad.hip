@@ -158,11 +158,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
 
 }  // namespace
 
-extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2,
-                            double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
-                            double* grad) {
-  if (!h) return GPK_BAD_ARG;
-  GPK_REQUIRE(h, X && ls && alpha && Kinv && grad, "lml_grad: null pointer");
+// the launches of gpk_lml_grad: the GW raw sums (before the factors of gpk_lml_grad's last lines) to dout (device)
+int gpk_lml_grad_enqueue(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, const double* alpha,
+                         int P, const double* Kinv, int64_t ldk, double* dout) {
+  GPK_REQUIRE(h, X && ls && alpha && Kinv, "lml_grad: null pointer");
   GPK_REQUIRE(h, N >= 1 && D >= 1 && D <= DMAXG && P >= 1 && P <= GPK_MAX_P, "lml_grad: D must be in [1, 16], P in [1, 16]");
   const int64_t Np = gpk_padded(N);
   GPK_REQUIRE(h, ldk >= Np && ldk % 2 == 0 && ((uintptr_t)Kinv % 16) == 0, "lml_grad: Kinv must be padded and 16-byte aligned");
@@ -177,20 +176,64 @@ extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, con
   void* ws = nullptr;
   GPK_TRY(gpk_scratch(h, (size_t)(nblocks + 1) * GW * sizeof(double), &ws));
   double* partial = (double*)ws;
-  double* out = partial + (size_t)nblocks * GW;
   gpk_time_begin(h, GPK_TIMED_GRAD);
   hipLaunchKernelGGL(lml_grad_kernel, dim3(nblocks), dim3(256), 0, h->stream, X, (long long)N, D, l, sf2, alpha, P,
                      Kinv, (long long)ldk, (long long)ntiles, partial);
   gpk_time_end(h);
   GPK_LAUNCH_CHECK(h);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(GW), dim3(256), 0, h->stream, (const double*)partial,
-                     nblocks, out);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(GW), dim3(256), 0, h->stream, (const double*)partial, nblocks, dout);
   GPK_LAUNCH_CHECK(h);
-  double host[GW];
-  GPK_CHECK_HIP(h, hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, h->stream));
-  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  return GPK_OK;
+}
+
+static void grad_from_sums(const double* host, int D, double noise, double* grad) {
   for (int d = 0; d < D; ++d) grad[d] = 0.5 * host[d];
   grad[D] = 0.5 * noise * host[DMAXG];
   grad[D + 1] = 0.5 * host[DMAXG + 1];
+}
+
+extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2,
+                            double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
+                            double* grad) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, grad, "lml_grad: null pointer");
+  double* dout = h->d_small + 64;
+  GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls, sf2, alpha, P, Kinv, ldk, dout));
+  double host[GW];
+  GPK_CHECK_HIP(h, hipMemcpyAsync(host, dout, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  grad_from_sums(host, D, noise, grad);
+  return GPK_OK;
+}
+
+// One evaluation of the log-marginal likelihood (and its gradient) as ONE chain of launches with ONE synchronisation: what the
+// estimator's optimiser loop runs per trial theta.  At the reference's own size (N = 1000) the three host round trips of the
+// call-by-call route - the pivot check of gpk_potrf, gpk_lml_terms, gpk_lml_grad - are a seventh of an evaluation.
+extern "C" int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, double diag_add,
+                            double noise, const double* Yn, int P, double* K, int64_t Np, double* winv, double* W, double* work,
+                            double* alpha, double* Kinv, double* terms, double* grad, int* info) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X && ls && Yn && K && winv && W && work && alpha && terms && info, "lml_eval: null pointer");
+  GPK_REQUIRE(h, h->batch == 1, "lml_eval: not available in batched mode");
+  GPK_REQUIRE(h, Np == gpk_padded(N) && P >= 1 && P <= GPK_MAX_P, "lml_eval: bad sizes");
+  GPK_REQUIRE(h, grad == nullptr || Kinv != nullptr, "lml_eval: the gradient needs the Kinv buffer");
+  GPK_TRY(gpk_gram(h, GPK_F64, X, N, D, ls, sf2, diag_add, K, Np));
+  GPK_TRY(gpk_potrf_enqueue(h, K, Np, Np, winv));
+  GPK_TRY(gpk_trtri(h, K, Np, Np, winv, W, Np, work));
+  GPK_TRY(gpk_potrs_inv(h, W, Np, Np, Yn, N, P, alpha));
+  double* dterms = h->d_small;            // [0, 1 + P): the terms; [64, 64 + GW): the gradient sums; then the pivot failure
+  double* dgrad = h->d_small + 64;
+  GPK_TRY(gpk_lml_terms_enqueue(h, K, N, Np, Yn, alpha, P, dterms));
+  if (grad) {
+    GPK_TRY(gpk_wtw(h, W, Np, Np, Kinv, Np));
+    GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls, sf2, alpha, P, Kinv, Np, dgrad));
+  }
+  int hinfo[GPK_MAX_BATCH] = {0};
+  GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, (64 + GW) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+  GPK_TRY(gpk_potrf_finish(h, hinfo, info));      // GPK_NOT_PD: what follows the factorisation ran on a finite, meaningless factor
+  for (int i = 0; i < 1 + P; ++i) terms[i] = h->h_small[i];
+  if (grad) grad_from_sums(h->h_small + 64, D, noise, grad);
   return GPK_OK;
 }

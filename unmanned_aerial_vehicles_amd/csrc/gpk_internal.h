@@ -114,6 +114,13 @@ constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 3 * 8 * 512;   // t
 int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used);
 int gpk_potrf_ptile_check(gpk_handle h);
 void gpk_model_free(gpk_handle h);   // gpk_model.hip
+// the launches of gpk_potrf / gpk_lml_terms / gpk_lml_grad without their synchronisations (gpk_lml_eval)
+int gpk_potrf_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv);
+int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info);
+int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
+                          double* dout);
+int gpk_lml_grad_enqueue(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, const double* alpha,
+                         int P, const double* Kinv, int64_t ldk, double* dout);
 
 // Event brackets of gpk_timing (no-ops unless enabled): record the first event, launch, record the second.
 constexpr int GPK_TIMING_RING = 64;

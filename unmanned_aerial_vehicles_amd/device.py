@@ -258,6 +258,40 @@ class DeviceGP:
                                          g.ctypes.data_as(_lib._dp)))
         return g
 
+    def lml_eval(self, ls, sf2, diag_add, noise, eval_gradient=True):
+        """One optimiser evaluation as one chain with one synchronisation (gpk_lml_eval): K1, K2, W = L^-1, alpha, K6a and -
+        eval_gradient - K^-1 and K6b; the model is left factored at these hyper-parameters.  Returns (log-det / 2,
+        [y_p . alpha_p], gradient as lml_grad or None).  Raises NotPositiveDefinite.  For Np <= INVERSE_EAGER_NP (where
+        alpha goes through the inverse factor anyway)."""
+        torch = _torch()
+        if eval_gradient and self.D > 16:
+            raise ValueError("analytic LML gradients support D <= 16")
+        self._ensure_K()
+        ls = np.ascontiguousarray(np.broadcast_to(np.asarray(ls, dtype=np.float64), (self.D,)))
+        be = self.be
+        self._f32 = None
+        self._Winv = {}
+        self.factored = False
+        W = be.empty((self.Np, self.Np), torch.float64)
+        work = be.empty(((self.Np // 2 + 128) ** 2,), torch.float64)
+        if eval_gradient and self._Kinv is None:
+            self._Kinv = be.empty((self.Np, self.Np), torch.float64)
+        terms = np.zeros(1 + self.P)
+        g = np.zeros(self.D + 2) if eval_gradient else None
+        info = C.c_int(0)
+        with be.lock:
+            be.bind_stream()
+            self.ls, self.sf2 = ls, float(sf2)
+            be.check(be.lib.gpk_lml_eval(
+                be.h, _p(self.X), self.N, self.D, ls.ctypes.data_as(_lib._dp), float(sf2), float(diag_add), float(noise),
+                _p(self.Yn), self.P, _p(self.K), self.Np, _p(self.winv), _p(W), _p(work), _p(self.alpha),
+                _p(self._Kinv) if eval_gradient else None, terms.ctypes.data_as(_lib._dp),
+                g.ctypes.data_as(_lib._dp) if eval_gradient else None, C.byref(info)))
+        self.factored = True
+        self._Winv["f64"] = W
+        self._amp = self._alpha_sq = self._batch_gate = None
+        return terms[0], terms[1:], g
+
     def release_grad_buffers(self):
         self._Kinv = None
 

@@ -159,13 +159,22 @@ class GaussianProcessRegressor:
         kern = self.kernel_.clone_with_theta(theta)
         comp = kern.components()
         D = self.n_features_in_
+        N = dev.N
+        if dev.Np <= dev.INVERSE_EAGER_NP and D <= 16:
+            # the whole evaluation as one chain of launches with one synchronisation (gpk_lml_eval)
+            try:
+                logdet_half, quad, g = dev.lml_eval(comp.ls_vector(D), comp.sf2, (comp.noise or 0.0) + float(self.alpha),
+                                                    comp.noise or 0.0, eval_gradient)
+            except NotPositiveDefinite:
+                return (-np.inf, np.zeros_like(theta)) if eval_gradient else -np.inf
+            lml = float(np.sum(-0.5 * quad - logdet_half - 0.5 * N * LOG_2PI))
+            return (lml, comp.map_gradient(g, D)) if eval_gradient else lml
         try:
             dev.factorize(comp.ls_vector(D), comp.sf2, (comp.noise or 0.0) + float(self.alpha))
         except NotPositiveDefinite:
             return (-np.inf, np.zeros_like(theta)) if eval_gradient else -np.inf
         dev.solve_alpha()
         logdet_half, quad = dev.lml_terms()
-        N = dev.N
         lml = float(np.sum(-0.5 * quad - logdet_half - 0.5 * N * LOG_2PI))
         if not eval_gradient:
             return lml
