@@ -710,3 +710,22 @@ def test_model_evaluator_on_the_reference_grid(csv_data, tmp_path):
     s = res["summary"]
     assert abs(s["mean_uncertainty"] - float(ref["printed_mean_uncertainty"])) < 5.1e-5
     assert abs(100 * s["high_confidence"] - float(ref["printed_high_pct"])) < 0.051
+
+
+def test_optimiser_restarts_side_by_side_give_the_same_model(csv_data):
+    """`n_restarts_optimizer` > 0 (src/px4/simple_gp.py:167-177 trains with one restart): the runs are independent, so the
+    estimator runs them side by side on private handles and streams - the starts are the ones scikit-learn would draw
+    (same generator, same order, _gpr.py:316-327), every evaluation is deterministic, so the selected theta, its LML and the
+    fitted alpha are bit-identical to running them one after the other."""
+    from unmanned_aerial_vehicles_amd import GaussianProcessRegressor, RBF, WhiteKernel
+    X, Y = csv_data["X10"][:600], csv_data["Y6"][:600]
+    models = []
+    for side_by_side in (True, False):
+        g = GaussianProcessRegressor(kernel=RBF(0.5, (1e-2, 1e2)) + WhiteKernel(0.1, (1e-5, 1e1)), alpha=1e-4, normalize_y=True,
+                                     n_restarts_optimizer=2, random_state=42)
+        g.concurrent_restarts = side_by_side
+        models.append(g.fit(X, Y))
+    a, b = models
+    assert np.array_equal(a.kernel_.theta, b.kernel_.theta)
+    assert a.log_marginal_likelihood_value_ == b.log_marginal_likelihood_value_
+    assert np.array_equal(a.alpha_, b.alpha_)

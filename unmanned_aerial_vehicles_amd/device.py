@@ -98,6 +98,23 @@ def get_backend(device_index=None) -> Backend:
         return b
 
 
+_workers = {}
+
+
+def worker_backends(device_index, n):
+    """n private (Backend, torch stream) pairs on a GPU, created once and reused: independent pieces of work - the restarts of
+    the estimator's optimiser, the per-axis models of BatchedARDGP - run on them from host threads (ctypes releases the GIL),
+    so that one piece's latency-bound launches (a factorisation at the reference's sizes keeps 5-20 % of the matrix pipe busy)
+    overlap the other's."""
+    torch = _torch()
+    main = get_backend(device_index)
+    with _backends_lock:
+        pool = _workers.setdefault(main.device_index, [])
+        while len(pool) < n:
+            pool.append((Backend(main.device_index), torch.cuda.Stream(device=main.device)))
+        return pool[:n]
+
+
 def padded(n):
     return (int(n) + 127) // 128 * 128
 

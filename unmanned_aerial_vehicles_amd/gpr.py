@@ -99,15 +99,16 @@ class GaussianProcessRegressor:
                 lml, grad = self._lml_on_device(theta, eval_gradient=True)
                 return -lml, -grad
 
-            optima = [self._constrained_optimization(obj, self.kernel_.theta, self.kernel_.bounds)]
+            bounds = self.kernel_.bounds
+            starts = [self.kernel_.theta]
             if self.n_restarts_optimizer > 0:
-                bounds = self.kernel_.bounds
                 if not np.isfinite(bounds).all():
                     raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all "
                                      "bounds are finite.")
-                for _ in range(self.n_restarts_optimizer):
-                    theta0 = self._rng.uniform(bounds[:, 0], bounds[:, 1])
-                    optima.append(self._constrained_optimization(obj, theta0, bounds))
+                # (scikit-learn draws a restart's start after the previous run, _gpr.py:316-327 - from a generator the runs do
+                # not touch: drawing them up front gives the same starts)
+                starts += [self._rng.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(self.n_restarts_optimizer)]
+            optima = self._optimise_from(starts, bounds, obj, yn)
             vals = [o[1] for o in optima]
             self.kernel_.theta = optima[int(np.argmin(vals))][0]
             self.log_marginal_likelihood_value_ = -float(np.min(vals))
@@ -134,6 +135,40 @@ class GaussianProcessRegressor:
         self._alpha_host = None
         self._L_host = None
         return self
+
+    # the restarts run side by side while all their device models together stay below this many bytes
+    CONCURRENT_RESTART_BYTES = 48e9
+
+    def _optimise_from(self, starts, bounds, obj, yn):
+        """One optimiser run per start, results in the order of `starts`.  The runs are independent (same data, their own
+        start): with more than one they run side by side, each on its own libgpk handle, stream and scratch model from its own
+        host thread - at the reference's sizes an evaluation is a chain of latency-bound launches that leaves most of the
+        chip idle, and two chains interleave.  Same results as one after the other (every run is deterministic)."""
+        n = len(starts)
+        per_run = 3.3 * self._dev.Np * self._dev.Np * 8.0
+        if n == 1 or not getattr(self, "concurrent_restarts", True) or n * per_run > self.CONCURRENT_RESTART_BYTES:
+            return [self._constrained_optimization(obj, t0, bounds) for t0 in starts]
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from .device import worker_backends
+        workers = worker_backends(self._dev.be.device_index, n)
+        torch.cuda.current_stream(self._dev.be.device).synchronize()
+
+        def run(i):
+            be, stream = workers[i]
+            with torch.cuda.stream(stream):
+                dev = DeviceGP(self.X_train_, yn, be)
+
+                def obj_i(theta):
+                    lml, grad = self._lml_on_device(theta, True, dev)
+                    return -lml, -grad
+
+                out = self._constrained_optimization(obj_i, starts[i], bounds)
+                stream.synchronize()
+            return out
+
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            return list(ex.map(run, range(n)))
 
     def _comp_check(self):
         comp = self.kernel_.components()
