@@ -449,26 +449,21 @@ extern "C" int gpk_lml(gpk_handle h, const double* theta, int n_theta, double* l
     GPK_TRY(dev_alloc(h, &m->salpha, (size_t)m->N * P));
   }
   if (grad && !m->sKinv) GPK_TRY(dev_alloc(h, &m->sKinv, nn));
-  GPK_TRY(gpk_gram(h, GPK_F64, m->X, m->N, D, ls, m->sf2, noise + m->jitter, m->sK, m->Np));
+  // the whole evaluation as one chain of launches with one synchronisation (gpk_lml_eval)
   int info = 0;
-  const int rc = gpk_potrf(h, m->sK, m->Np, m->Np, m->swinv, &info);
+  double terms[1 + GPK_MAX_P], g[GPK_MAX_D_PREDICT + 2];
+  const int rc = gpk_lml_eval(h, m->X, m->N, D, ls, m->sf2, noise + m->jitter, noise, m->Yn, P, m->sK, m->Np, m->swinv, m->sW,
+                              m->sT, m->salpha, grad ? m->sKinv : nullptr, terms, grad ? g : nullptr, &info);
   if (rc == GPK_NOT_PD) {            // inside an optimiser: LML = -inf, zero gradient (_gpr.py:586-589)
     *lml = -std::numeric_limits<double>::infinity();
     if (grad) for (int i = 0; i < n_theta; ++i) grad[i] = 0.0;
     return GPK_OK;
   }
   GPK_TRY(rc);
-  GPK_TRY(gpk_trtri(h, m->sK, m->Np, m->Np, m->swinv, m->sW, m->Np, m->sT));
-  GPK_TRY(gpk_potrs_inv(h, m->sW, m->Np, m->Np, m->Yn, m->N, P, m->salpha));
-  double terms[1 + GPK_MAX_P];
-  GPK_TRY(gpk_lml_terms(h, m->sK, m->N, m->Np, m->Yn, m->salpha, P, terms));
   double v = 0.0;
   for (int p = 0; p < P; ++p) v += -0.5 * terms[1 + p] - terms[0] - 0.5 * (double)m->N * std::log(2.0 * M_PI);
   *lml = v;
   if (grad) {
-    double g[GPK_MAX_D_PREDICT + 2];
-    GPK_TRY(gpk_wtw(h, m->sW, m->Np, m->Np, m->sKinv, m->Np));
-    GPK_TRY(gpk_lml_grad(h, m->X, m->N, D, ls, m->sf2, noise, m->salpha, P, m->sKinv, m->Np, g));
     if (nl == 1) { double s = 0.0; for (int d = 0; d < D; ++d) s += g[d]; grad[0] = s; }   // kernels.py:1574-1576
     else for (int d = 0; d < D; ++d) grad[d] = g[d];
     grad[nl] = g[D];
