@@ -621,9 +621,11 @@ def test_lml_gradient_kernels(be, csv_data, ka):
 @pytest.mark.parametrize("N,P,ard", [(1000, 3, False), (700, 1, True), (130, 6, False)])
 def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
     """gpk_lml_eval - the optimiser's evaluation as one chain of launches with one synchronisation - against the same
-    building blocks called one by one (three synchronisations): the same kernels in the same order, so the terms, the
-    gradient, alpha and the factor are bit-identical; value only (no K^-1) as well; a non-positive-definite trial matrix
-    raises as gpk_potrf does (sklearn/_gpr.py:586-589 turns that into -inf)."""
+    building blocks called one by one (three synchronisations): the factor and the terms are bit-identical (the
+    same tasks in the same order); alpha and the gradient are bit-identical when the inverse factor comes from the level-by-level
+    kernels (ptile_inv_max_np=0) and agrees to rounding when its tiles are tasks of the one-launch factorisation (the
+    default up to Np=5120: other summation order); K^-1 of that path against numpy; value only (no K^-1) as well; a
+    non-positive-definite trial matrix raises as gpk_potrf does (sklearn/_gpr.py:586-589 turns that into -inf)."""
     import torch
     from unmanned_aerial_vehicles_amd.device import DeviceGP, NotPositiveDefinite
     X, Y = csv_data["X10"][:N, :9], csv_data["Y6"][:N, :P]
@@ -636,8 +638,20 @@ def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
     g_a = a.lml_grad(0.1)
     b = DeviceGP(X, Yn, be)
     ld_b, quad_b, g_b = b.lml_eval(ls, 1.3, 0.1001, 0.1, True)
-    assert ld_a == ld_b and np.array_equal(quad_a, quad_b) and np.array_equal(g_a, g_b)
-    assert torch.equal(a.alpha, b.alpha) and torch.equal(torch.tril(a.K), torch.tril(b.K))
+    assert ld_a == ld_b and np.array_equal(quad_a, quad_b)
+    assert np.max(np.abs(g_a - g_b)) <= 1e-11 * np.max(np.abs(g_a))
+    assert torch.equal(torch.tril(a.K), torch.tril(b.K))
+    assert float((a.alpha - b.alpha).abs().max()) <= 1e-11 * float(a.alpha.abs().max())    # alpha is W^T (W y)
+    Kinv = b._Kinv.cpu().numpy()[:N, :N]
+    ref = np.linalg.inv(O.rbf_gram(X, ls, 1.3, 0.1001))
+    assert relerr(np.tril(Kinv), np.tril(ref)) < 1e-9
+    be.check(be.lib.gpk_set_option(be.h, b"ptile_inv_max_np", 0))
+    try:
+        b2 = DeviceGP(X, Yn, be)
+        ld_b2, quad_b2, g_b2 = b2.lml_eval(ls, 1.3, 0.1001, 0.1, True)
+    finally:
+        be.check(be.lib.gpk_set_option(be.h, b"ptile_inv_max_np", 5120))
+    assert ld_a == ld_b2 and np.array_equal(quad_a, quad_b2) and np.array_equal(g_a, g_b2) and torch.equal(a.alpha, b2.alpha)
     c = DeviceGP(X, Yn, be)
     ld_c, quad_c, g_c = c.lml_eval(ls, 1.3, 0.1001, 0.1, False)
     assert g_c is None and ld_c == ld_a and np.array_equal(quad_c, quad_a)

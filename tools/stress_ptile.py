@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Race hunt for the one-launch Cholesky's device-side protocol (ticket order, progress words, 16-column hand-overs): the same
 factorisation REPS times per shape - single problems and batches - every result bit-identical to the first and the launch never
-aborted; buffers poisoned with NaN before every run.    python tools/stress_ptile.py [REPS]"""
+aborted; buffers poisoned with NaN before every run; then the fused factor + inverse-factor launch the same way.    python tools/stress_ptile.py [REPS]"""
 import ctypes as C
 import os
 import sys
@@ -51,6 +51,26 @@ def main():
                 bad += 1
                 print(f"MISMATCH N={n} B={B} run {r}: |dL| {float((L - ref[0]).abs().max()):.3e}", flush=True)
         print(f"N={n:5d} B={B}: {reps} runs bit-identical" if bad == 0 else f"N={n} B={B}: {bad} mismatches so far", flush=True)
+    # factor + inverse factor in the one launch (gpk_lml_eval with a gradient, Np <= ptile_inv_max_np): gradient and K^-1
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    for n, P in ((640, 1), (1000, 3), (2048, 1), (3000, 2), (4096, 3), (5120, 1)):
+        rng = np.random.default_rng(n)
+        X = rng.standard_normal((n, 7))
+        Yn = rng.standard_normal((n, P))
+        dev = DeviceGP(X, Yn, be)
+        ref = None
+        for r in range(reps):
+            if getattr(dev, "_Kinv", None) is not None:
+                dev._Kinv.fill_(float("nan"))
+            ld, quad, g = dev.lml_eval(1.5, 1.0, 0.0501, 0.05, True)
+            Ki = torch.tril(dev._Kinv[:n, :n])
+            if ref is None:
+                ref = (ld, quad.copy(), g.copy(), Ki.clone())
+                assert bool(torch.isfinite(Ki).all()) and np.isfinite(g).all()
+            elif not (ld == ref[0] and np.array_equal(quad, ref[1]) and np.array_equal(g, ref[2]) and torch.equal(Ki, ref[3])):
+                bad += 1
+                print(f"MISMATCH fused N={n} P={P} run {r}: |dKinv| {float((Ki - ref[3]).abs().max()):.3e}", flush=True)
+        print(f"fused N={n:5d} P={P}: {reps} runs bit-identical" if bad == 0 else f"fused N={n} P={P}: {bad} mismatches so far", flush=True)
     print(f"{'OK' if bad == 0 else 'FAILED'}: {bad} mismatches, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 

@@ -716,6 +716,61 @@ int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const d
 
 }  // namespace
 
+namespace {
+__global__ void zero_band_kernel(double* __restrict__ W0, long long Np, long long ldw, long long strideW);   // (defined with gpk_trtri)
+// W (lower tiles, strictly below the block diagonal) from W^T (upper tiles): 64 x 64 pieces transposed through LDS
+__global__ __launch_bounds__(256) void mirror_lower_kernel(const double* __restrict__ Wt, long long ldt, double* __restrict__ W,
+                                                           long long ldw, int nt) {
+  __shared__ double t[64][65];
+  // blockIdx.x: piece (a, b), a, b in 0..1, of tile pair p = (i, j), i > j, enumerated row by row
+  const int piece = blockIdx.x & 3, pr = blockIdx.x >> 2;
+  int i = (int)((1.0f + __builtin_sqrtf(8.0f * (float)pr + 1.0f)) * 0.5f);
+  while (i * (i - 1) / 2 > pr) --i;
+  while ((i + 1) * i / 2 <= pr) ++i;
+  const int j = pr - i * (i - 1) / 2;
+  if (i >= nt) return;
+  const int a = piece >> 1, b = piece & 1;
+  // source: rows of tile (j, i) of W^T: rows 128 j + 64 b .., columns 128 i + 64 a ..;  destination: tile (i, j) of W
+  const double* src = Wt + ((long long)(128 * j + 64 * b)) * ldt + 128 * i + 64 * a;
+  double* dst = W + ((long long)(128 * i + 64 * a)) * ldw + 128 * j + 64 * b;
+  const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  for (int r = r0; r < 64; r += 4) t[r][c] = src[(long long)r * ldt + c];
+  __syncthreads();
+  for (int r = r0; r < 64; r += 4) dst[(long long)r * ldw + c] = t[c][r];
+}
+}  // namespace
+
+// Factor AND inverse factor as one persistent launch (gpk_ptile.hip with the tiles of W^T in its task list) + a transposing copy:
+// for matrices small enough that the factorisation leaves most of the chip idle (h->ptile_inv_max_np).  wt: Np x lda scratch.
+// *used = 0: not served (the caller runs gpk_potrf_enqueue + gpk_trtri).
+int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, double* W, int64_t ldw, double* wt,
+                            int* used) {
+  *used = 0;
+  if (!wt || h->batch != 1 || Np > h->ptile_inv_max_np || ldw != lda || ((uintptr_t)wt % 128) != 0) return GPK_OK;
+  GPK_REQUIRE(h, A && winv && W, "potrf: null pointer");
+  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, h->batch * sizeof(int), h->stream));
+  gpk_time_begin(h, GPK_TIMED_POTRF);
+  h->ptile_launches = 0;
+  const int rc = gpk_potrf_ptile(h, A, Np, lda, winv, 0, used, wt);
+  gpk_time_end(h);
+  GPK_TRY(rc);
+  if (!*used) return GPK_OK;
+  const int64_t nl = Np / NB;
+  // the diagonal tiles of W from the tile inverses, zeros right of them (what the lockstep launches read), the rest mirrored
+  const unsigned ny = (unsigned)(((GPK_ZERO_BAND_TILES - 1) * NB + 255) / 256);
+  hipLaunchKernelGGL(zero_band_kernel, dim3((unsigned)Np, ny, 1), dim3(256), 0, h->stream, W, (long long)Np, (long long)ldw, 0ll);
+  GPK_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, (unsigned)nl, 1), dim3(256), 0, h->stream, winv, W, (long long)ldw,
+                     (long long)(NB * NB * sizeof(double)), (long long)(NB * (ldw + 1) * sizeof(double)), 0ll, 0ll);
+  GPK_LAUNCH_CHECK(h);
+  if (nl > 1) {
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)(nl * (nl - 1) / 2 * 4)), dim3(256), 0, h->stream, wt, (long long)lda,
+                       W, (long long)ldw, (int)nl);
+    GPK_LAUNCH_CHECK(h);
+  }
+  return GPK_OK;
+}
+
 // The launches of gpk_potrf without its synchronisation (gpk_lml_eval queues the rest of an evaluation behind them);
 // gpk_potrf_finish reads the pivot failures back once the stream has been synchronised.
 int gpk_potrf_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv) {

@@ -218,8 +218,13 @@ extern "C" int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, con
   GPK_REQUIRE(h, Np == gpk_padded(N) && P >= 1 && P <= GPK_MAX_P, "lml_eval: bad sizes");
   GPK_REQUIRE(h, grad == nullptr || Kinv != nullptr, "lml_eval: the gradient needs the Kinv buffer");
   GPK_TRY(gpk_gram(h, GPK_F64, X, N, D, ls, sf2, diag_add, K, Np));
-  GPK_TRY(gpk_potrf_enqueue(h, K, Np, Np, winv));
-  GPK_TRY(gpk_trtri(h, K, Np, Np, winv, W, Np, work));
+  // small matrices, gradient wanted (Kinv is free until W^T W writes it): factor and inverse factor as ONE persistent launch
+  int fused = 0;
+  if (grad) GPK_TRY(gpk_potrf_trtri_enqueue(h, K, Np, Np, winv, W, Np, Kinv, &fused));
+  if (!fused) {
+    GPK_TRY(gpk_potrf_enqueue(h, K, Np, Np, winv));
+    GPK_TRY(gpk_trtri(h, K, Np, Np, winv, W, Np, work));
+  }
   GPK_TRY(gpk_potrs_inv(h, W, Np, Np, Yn, N, P, alpha));
   double* dterms = h->d_small;            // [0, 1 + P): the terms; [64, 64 + GW): the gradient sums; then the pivot failure
   double* dgrad = h->d_small + 64;

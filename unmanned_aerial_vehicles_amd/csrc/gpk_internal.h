@@ -51,6 +51,7 @@ struct gpk_context {
   int ptile_max_np = 16384;
   int ptile_prog_max_nt = 128;  // ... up to this many tile columns the two tiles under a diagonal tile follow that tile's factorisation 16
                              // columns at a time instead of waiting for the whole inverse (GPK_PTILE_PROG_NT; 0: never)
+  int ptile_inv_max_np = 5120;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (GPK_PTILE_INV_NP; 0: never)
   int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so (GPK_PTILE_PROG_ROWS)
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
@@ -107,16 +108,18 @@ struct gpk_context {
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
 
 // ---- one-launch tile Cholesky (gpk_ptile.hip) -----------------------------------------
-constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 3 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
+constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 4 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
                                                         // counters; one pause word per CU; per tile row: 16-column steps of the diagonal
                                                         // tile / of the tile left of it / of the tile left of that one published so far
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
-int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used);
+int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt = nullptr);
 int gpk_potrf_ptile_check(gpk_handle h);
 void gpk_model_free(gpk_handle h);   // gpk_model.hip
 // the launches of gpk_potrf / gpk_lml_terms / gpk_lml_grad without their synchronisations (gpk_lml_eval)
 int gpk_potrf_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv);
 int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info);
+int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, double* W, int64_t ldw, double* wt,
+                            int* used);   // factor + inverse factor as one persistent launch (small matrices), or *used = 0
 int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
                           double* dout);
 int gpk_lml_grad_enqueue(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, const double* alpha,

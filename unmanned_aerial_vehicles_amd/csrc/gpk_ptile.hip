@@ -73,6 +73,7 @@ constexpr int PAUSE_OFF = 16 + 8 * 512;       // ctrl ints: one word per compute
 constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "block rows 0 .. v - 1 of L_jj and their W_bb are final"
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
 constexpr int YPROG_OFF = XPROG_OFF + 8 * 512; // ctrl ints: per tile row i, likewise for tile (i, i - 2)
+constexpr int WT_OFF = YPROG_OFF + 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
 constexpr int XS = 18;                        // row stride (doubles) of a wave's 16 x 16 output staging block
 static_assert((22 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: two L images, the waves' W blocks and staging blocks");
 
@@ -86,6 +87,8 @@ struct PTParams {
   double* winv; long long strideW;
   int* info; int row0;
   int nt, batch, ntasks;
+  double* wt; long long strideWt;                  // non-null: the inverse factor's transpose W^T = L^-T by tiles as well (leading
+                                                   // dimension lda): nt tasks per tile column instead of nt - column
   int prog_rows;                                   // ... how many tiles under a diagonal tile do so (1 or 2)
   int prog;                                        // latency-bound launch: the sub-diagonal tiles follow their diagonal tiles step by step
   int* ctrl;                                       // [0] ticket counter, [1] abort; ready counters from ctrl + 16;
@@ -164,6 +167,21 @@ __device__ int poll_ktiles2(const int* ra, const int* xa, const int* rb, const i
   }
 }
 
+// one lane, task (j, i) of W^T: spin until `need` tile columns from j on are final in row i of L (ready counts from column 0)
+// and in row j of W^T (wtready counts from the diagonal tile); -1 when the launch is aborted
+__device__ int poll_inv(const int* ready_i, int j, const int* wtready_j, int need, int* abortp) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int it = 0;; ++it) {
+    const int v = min(ld_agent(ready_i) - j, ld_agent(wtready_j));
+    if (v >= need) return v;
+    if ((it & 31) == 31) {
+      if (ld_agent(abortp) != 0) return -1;
+      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GPK_PTILE_TIMEOUT_TICKS) { st_agent(abortp, 1); st_agent(abortp + (GPK_PTILE_CTRL_INTS - 1), 1); return -1; }
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 // one lane: spin until *p == 0; -1 when the launch is aborted
 __device__ int poll_clear(const int* p, int* abortp) {
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -236,14 +254,28 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     if (task >= p.ntasks) return;
     PT_STAMP(0);
     if (p.trace && tid == 0) p.trace[(long long)task * 16 + 14] = (long long)__builtin_readcyclecounter();
-    // task -> (problem b, tile row i, tile column j); column-major list: column j starts at j nt - j (j - 1) / 2
+    // task -> (problem b, tile row i, tile column j); column-major list: column j starts at j nt - j (j - 1) / 2.
+    // With the inverse factor in the launch (p.wt) a column has nt tasks: the diagonal tile, the nt - 1 - c tiles under it, and
+    // the c tiles (j, c), j < c, of W^T = L^-T that the diagonal tile c closes - task (i, j) with i < j below:
+    //   W^T(i, j) = -(sum_{k=i}^{j-1} W^T(i, k) L(j, k)^T) W_jj^T
+    // is the task of a tile under the diagonal on another pair of panels (own rows: row panel i of W^T; the other operand:
+    // row panel j of L, both k-contiguous), its k-loop can run as soon as row j of L is final, and its closing product is
+    // the same multiplication by W_jj^T.  The factorisation keeps a fifth of the matrix pipe busy at the sizes the reference
+    // trains at: these tasks run in the rest.
     const int b = task % p.batch;
     const long long tt = task / p.batch;
-    int j = (int)(((double)(2 * nt + 1) - __builtin_sqrt((double)(2 * nt + 1) * (2 * nt + 1) - 8.0 * (double)tt)) * 0.5);
-    j = max(0, min(j, nt - 1));
-    while (j > 0 && (long long)j * nt - (long long)j * (j - 1) / 2 > tt) --j;
-    while ((long long)(j + 1) * nt - (long long)(j + 1) * j / 2 <= tt) ++j;
-    const int i = j + (int)(tt - ((long long)j * nt - (long long)j * (j - 1) / 2));
+    int i, j;
+    if (p.wt) {
+      const int c = (int)(tt / nt), r = (int)(tt - (long long)c * nt);
+      j = c;
+      i = r < nt - c ? c + r : r - (nt - c);
+    } else {
+      j = (int)(((double)(2 * nt + 1) - __builtin_sqrt((double)(2 * nt + 1) * (2 * nt + 1) - 8.0 * (double)tt)) * 0.5);
+      j = max(0, min(j, nt - 1));
+      while (j > 0 && (long long)j * nt - (long long)j * (j - 1) / 2 > tt) --j;
+      while ((long long)(j + 1) * nt - (long long)(j + 1) * j / 2 <= tt) ++j;
+      i = j + (int)(tt - ((long long)j * nt - (long long)j * (j - 1) / 2));
+    }
     (void)ntp;
     double* A = reinterpret_cast<double*>(reinterpret_cast<char*>(p.A) + (long long)b * p.strideA);
     double* Wv = reinterpret_cast<double*>(reinterpret_cast<char*>(p.winv) + (long long)b * p.strideW);
@@ -252,7 +284,10 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     int* xprog = p.ctrl + XPROG_OFF + b * nt + i;    // tile (i, i - 1): 16-column blocks published so far
     int* yprog = p.ctrl + YPROG_OFF + b * nt + i;    // tile (i, i - 2): likewise
     const long long lda = p.lda;
-    double* Atile = A + (long long)i * TS * lda + (long long)j * TS;
+    double* Wt = p.wt ? reinterpret_cast<double*>(reinterpret_cast<char*>(p.wt) + (long long)b * p.strideWt) : nullptr;
+    int* wtready = p.ctrl + WT_OFF + b * nt;
+    const bool inv = i < j;                              // a tile of W^T (the output, and the own rows, are in Wt)
+    double* Atile = (inv ? Wt : A) + (long long)i * TS * lda + (long long)j * TS;
     const bool diag = (i == j);
     // One body per task kind, instantiated twice: the two kinds then have their own accumulators.  (As one body with
     // run-time branches the accumulators of both k-loops meet in phi nodes and the register allocator, at its 128-register
@@ -260,6 +295,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     auto run = [&](auto dc) -> bool {
       constexpr bool DIAG = decltype(dc)::value == 1;
       constexpr bool PROG = decltype(dc)::value == 2;    // the tile under a diagonal tile in a launch bound by the diagonal chain
+      constexpr bool INV = decltype(dc)::value == 3;     // a tile of W^T (i < j)
       // the diagonal task IS the critical path: its waves go first wherever they share a SIMD with another workgroup's
       __builtin_amdgcn_s_setprio(DIAG ? 3 : 0);
       // block row owned by this wave: the diagonal task pairs a long and a short row on every SIMD (waves w, w + 4)
@@ -274,26 +310,31 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         const double* src = Atile + (long long)(16 * rw + lr) * lda + lq;
         sfor<0, 8>([&](auto kc) {          // (a diagonal task reads its blocks right of the diagonal too: valid memory,
           constexpr int KB = decltype(kc)::value;   //  they ride along through the k-loop and are dropped after it)
+          if constexpr (!INV) {                     // (a tile of W^T starts from zero)
   #pragma unroll
-          for (int t = 0; t < 4; ++t) S[KB][t] = src[16 * KB + 4 * t];
+            for (int t = 0; t < 4; ++t) S[KB][t] = src[16 * KB + 4 * t];
+          }
         });
       }
 
       // ---- k-loop over the finished tile columns 0 .. j - 1 (8 k-tiles each), register-staged pipeline as in gpk_gemm.hip
-      const int nkt = 8 * j;
+      // (a tile of W^T: tile columns i .. j - 1 of row panel j of L and of row panel i of W^T)
+      const int ncol = INV ? j - i : j;
+      const int nkt = 8 * ncol;
       if (nkt > 0) {
-        const char* pj = reinterpret_cast<const char*>(A + (long long)j * TS * lda);     // row panel j: A operand
-        const char* pi = reinterpret_cast<const char*>(A + (long long)i * TS * lda);     // row panel i: B operand
+        const char* pj = reinterpret_cast<const char*>(A + (long long)j * TS * lda + (INV ? (long long)i * TS : 0));   // A operand
+        const char* pi = reinterpret_cast<const char*>((INV ? Wt : A) + (long long)i * TS * lda + (INV ? (long long)i * TS : 0));   // B operand: the own rows
         int avail = 0;                                   // tile columns known to be final in rows i and j
         auto need_cols = [&](int need) -> bool {        // uniform; false = aborted
           if (avail >= need) return true;
-          if (tid == 0) ctl[1] = poll_ready(ready + i, DIAG ? nullptr : ready + j, need, abortp);
+          if (tid == 0) ctl[1] = INV ? poll_inv(ready + j, i, wtready + i, need, abortp)
+                                     : poll_ready(ready + i, DIAG ? nullptr : ready + j, need, abortp);
           __syncthreads();
           const int v = ctl[1];
           __syncthreads();
           if (v < 0) return false;
-          avail = min(v, j);
-          if (avail >= j) PT_STAMP(11);
+          avail = min(v, ncol);
+          if (avail >= ncol) PT_STAMP(11);
 
           return true;
         };
@@ -652,6 +693,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         PT_STAMP(4);
         }
         __syncthreads();                                            // every wave is done with the W image
+        // (a tile of W^T needs no sign change: the k-loop accumulates MINUS the products, as the factor's update does)
         // S[mb][t] (lane n = lr, q = lq) = L_ij[16 w + n][16 mb + q + 4 t]: through LDS in two column halves, then
         // whole 512-byte row pieces with 16-byte sc1 stores
         double* ob = reinterpret_cast<double*>(lds);
@@ -675,7 +717,8 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         wait_vm0();
         __syncthreads();
         if (tid == 0) {
-          st_agent(ready + i, j + 1);
+          if constexpr (INV) st_agent(wtready + i, j - i + 1);
+          else st_agent(ready + i, j + 1);
           if (i == j + 1) st_agent(pausep, 0);
         }
         PT_STAMP(5);
@@ -788,6 +831,11 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   #pragma unroll
           for (int t = 0; t < 4; ++t)
             __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (Wt) {                                                 // W_jj^T, the diagonal tile of W^T: entry (16 rw + n, 16 JB + q + 4 t)
+            double* dt = Wt + (long long)j * TS * (lda + 1) + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) __hip_atomic_store(dt + 4 * t, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (rw == JB) {                                           // L_bb: lower triangle only (the tile's upper part stays)
             double* dl = Atile + (long long)(16 * JB + lr) * lda + 16 * JB + lq;
   #pragma unroll
@@ -804,9 +852,16 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         // steps, while the previous column's tiles are being published - and the wait stalled every step by 800 cycles or
         // more.)  The last step publishes a phase early instead (above), and the end of the task everything.
         // (p.prog = 0: a launch without the 16-column hand-overs - the A/B switch ptile_prog_max_nt.)
+        // (with W^T in the launch the waves of the inverse columns issue four more stores per step: 8, the factoring wave 12)
         if (p.prog) {
-          if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          if (Wt) {
+            if (rw > JB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rw == JB - 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          } else {
+            if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          }
         }
         if (rw == JB + 1) PT_SUB(11);
         __syncthreads();
@@ -817,6 +872,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
       __syncthreads();
       if (tid == 0) {
         st_agent(wprog, 8);
+        if (Wt) st_agent(wtready + j, 1);
         st_agent(ready + j, j + 1);
         st_agent(pausep, 0);
       }
@@ -826,7 +882,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
       return true;
     };
     // (one instantiation per task kind: each has its own accumulators, see above)
-    if (!(diag ? run(IC<1>{}) : (p.prog && i <= j + p.prog_rows) ? run(IC<2>{}) : run(IC<0>{}))) return;
+    if (!(diag ? run(IC<1>{}) : inv ? run(IC<3>{}) : (p.prog && i <= j + p.prog_rows) ? run(IC<2>{}) : run(IC<0>{}))) return;
   }
 }
 
@@ -834,7 +890,9 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
 
 // Factor the Np x Np matrix A (lower triangle, in place) and write the inverses of its diagonal tiles to winv, one launch.
 // Returns GPK_OK with *used = 0 when the shape is not served here (the caller then runs the recursion).
-int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used) {
+// wt (optional): an Np x lda scratch that receives W^T = L^-T by tiles (upper tiles and the diagonal ones; everything else is left
+// alone) - only when the whole matrix is this one launch (row0 == 0).
+int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt) {
   *used = 0;
   // (three tiles and fewer stay with the launch chain - four launches: nothing to gain, and the factor keeps the bits
   // that the optimiser-path parity test of the 240-row trainer fixture was pinned with)
@@ -842,7 +900,7 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   if (((uintptr_t)A % 128) != 0 || (lda % 16) != 0 || ((uintptr_t)winv % 128) != 0) return GPK_OK;
   const int nt = (int)(Np / TS);
   const int nb = h->batch;
-  const long long ntasks = (long long)nt * (nt + 1) / 2 * nb;
+  const long long ntasks = (wt ? (long long)nt * nt : (long long)nt * (nt + 1) / 2) * nb;
   const size_t ctrl_ints = 16 + (size_t)nb * nt;
   if (ntasks >= (1ll << 30) || ctrl_ints > (size_t)PAUSE_OFF) return GPK_OK;
   if (!h->d_ptile) {
@@ -861,6 +919,9 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   PTParams p;
   p.A = A; p.lda = lda; p.strideA = sA;
   p.winv = winv; p.strideW = sW;
+  p.wt = wt; p.strideWt = wt ? gpk_bstride(h, wt) : 0;
+  // (the tasks of W^T read whole tiles of it, the diagonal ones included, whose lower blocks nobody writes: zeros)
+  if (wt) GPK_CHECK_HIP(h, hipMemsetAsync(wt, 0, (size_t)Np * lda * sizeof(double), h->stream));
   p.info = h->d_info; p.row0 = row0;
   p.nt = nt; p.batch = nb; p.ntasks = (int)ntasks;
   p.prog = nt <= h->ptile_prog_max_nt ? 1 : 0;
