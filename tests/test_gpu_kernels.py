@@ -624,7 +624,7 @@ def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
     building blocks called one by one (three synchronisations): the factor and the terms are bit-identical (the
     same tasks in the same order); alpha and the gradient are bit-identical when the inverse factor comes from the level-by-level
     kernels (ptile_inv_max_np=0) and agrees to rounding when its tiles are tasks of the one-launch factorisation (the
-    default up to Np=5120: other summation order); K^-1 of that path against numpy; value only (no K^-1) as well; a
+    default up to Np=4608: other summation order); K^-1 of that path against numpy; value only (no K^-1) as well; a
     non-positive-definite trial matrix raises as gpk_potrf does (sklearn/_gpr.py:586-589 turns that into -inf)."""
     import torch
     from unmanned_aerial_vehicles_amd.device import DeviceGP, NotPositiveDefinite
@@ -650,7 +650,7 @@ def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
         b2 = DeviceGP(X, Yn, be)
         ld_b2, quad_b2, g_b2 = b2.lml_eval(ls, 1.3, 0.1001, 0.1, True)
     finally:
-        be.check(be.lib.gpk_set_option(be.h, b"ptile_inv_max_np", 5120))
+        be.check(be.lib.gpk_set_option(be.h, b"ptile_inv_max_np", 4608))
     assert ld_a == ld_b2 and np.array_equal(quad_a, quad_b2) and np.array_equal(g_a, g_b2) and torch.equal(a.alpha, b2.alpha)
     c = DeviceGP(X, Yn, be)
     ld_c, quad_c, g_c = c.lml_eval(ls, 1.3, 0.1001, 0.1, False)

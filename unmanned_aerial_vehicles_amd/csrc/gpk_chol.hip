@@ -435,8 +435,14 @@ __global__ __launch_bounds__(256) void trsm256_kernel(double* __restrict__ B0, l
 //                         lanes and waves once per row block
 //   pass 2  alpha = W^T Z: a workgroup owns (128-column chunk, segment of SEG rows); a wave reads whole row segments
 //                         (rows wave, wave + 4, ...), z_i is wave-uniform; partial column sums per segment, then a
-//                         reduction over the segments
-constexpr int K3_SEG = 2048;
+//                         reduction over the segments. SEG follows the size (k3_seg): 2048 rows from Np = 32768,
+//                         down to 128 at Np <= 4096, so that the launch has about 1000 workgroups at every size
+//                         (with 2048 rows, Np = 4096 was 48 workgroups of 512 rows per wave: 120 us for 67 MB)
+inline int k3_seg(int64_t Np) {
+  int seg = 128;
+  while (seg < 2048 && (long long)seg * 2 * 262144 <= (long long)Np * Np) seg *= 2;
+  return seg;
+}
 template <int P, int RB>
 __global__ __launch_bounds__(256) void k3_wy_kernel(const double* __restrict__ W, long long ldw, const double* __restrict__ Y,
                                                     long long N, double* __restrict__ Z, int nblk) {
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256) void k3_wy_kernel(const double* __restrict__ W
 
 template <int P>
 __global__ __launch_bounds__(256) void k3_wtz_kernel(const double* __restrict__ W, long long ldw, long long Np,
-                                                     const double* __restrict__ Z, double* __restrict__ part, int nseg) {
+                                                     const double* __restrict__ Z, double* __restrict__ part, int nseg, int K3_SEG) {
   typedef double dv2 __attribute__((ext_vector_type(2)));
   __shared__ double red[4][128 * P];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256) void k3_wtz_kernel(const double* __restrict__ 
 }
 
 template <int P>
-__global__ void k3_reduce_kernel(const double* __restrict__ part, long long Np, long long N, int nseg,
+__global__ void k3_reduce_kernel(const double* __restrict__ part, long long Np, long long N, int nseg, int K3_SEG,
                                  double* __restrict__ alpha) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= N * P) return;
@@ -543,7 +549,7 @@ __global__ void k3_reduce_kernel(const double* __restrict__ part, long long Np, 
 template <int P>
 int k3_stream(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const double* Y, int64_t N, double* alpha) {
   constexpr int RB = P <= 3 ? 16 : 8;
-  const int nseg = (int)((Np + K3_SEG - 1) / K3_SEG);
+  const int K3_SEG = k3_seg(Np), nseg = (int)((Np + K3_SEG - 1) / K3_SEG);
   void* ws = nullptr;
   GPK_TRY(gpk_scratch(h, ((size_t)Np * P + (size_t)nseg * Np * P) * sizeof(double), &ws));
   double* Z = (double*)ws;
@@ -552,10 +558,10 @@ int k3_stream(gpk_handle h, const double* W, int64_t Np, int64_t ldw, const doub
   hipLaunchKernelGGL((k3_wy_kernel<P, RB>), dim3((unsigned)nblk), dim3(256), 0, h->stream, W, (long long)ldw, Y, (long long)N, Z, nblk);
   GPK_LAUNCH_CHECK(h);
   hipLaunchKernelGGL((k3_wtz_kernel<P>), dim3((unsigned)nseg, (unsigned)(Np / 128)), dim3(256), 0, h->stream, W, (long long)ldw,
-                     (long long)Np, (const double*)Z, part, nseg);
+                     (long long)Np, (const double*)Z, part, nseg, K3_SEG);
   GPK_LAUNCH_CHECK(h);
   hipLaunchKernelGGL((k3_reduce_kernel<P>), dim3((unsigned)((N * P + 255) / 256)), dim3(256), 0, h->stream, (const double*)part,
-                     (long long)Np, (long long)N, nseg, alpha);
+                     (long long)Np, (long long)N, nseg, K3_SEG, alpha);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }

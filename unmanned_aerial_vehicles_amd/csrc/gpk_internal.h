@@ -51,7 +51,7 @@ struct gpk_context {
   int ptile_max_np = 16384;
   int ptile_prog_max_nt = 128;  // ... up to this many tile columns the two tiles under a diagonal tile follow that tile's factorisation 16
                              // columns at a time instead of waiting for the whole inverse (GPK_PTILE_PROG_NT; 0: never)
-  int ptile_inv_max_np = 5120;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (GPK_PTILE_INV_NP; 0: never)
+  int ptile_inv_max_np = 4608;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (GPK_PTILE_INV_NP; 0: never)
   int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so (GPK_PTILE_PROG_ROWS)
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU

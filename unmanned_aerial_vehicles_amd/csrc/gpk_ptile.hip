@@ -886,6 +886,12 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   }
 }
 
+// the diagonal tiles of W^T zeroed: the tasks of W^T read whole tiles, the diagonal task writes only the blocks on and
+// right of a diagonal tile's block diagonal
+__global__ void zero_diag_tiles_kernel(double* __restrict__ Wt, long long ldt) {
+  const long long r = blockIdx.x;
+  Wt[r * ldt + (r / TS) * TS + threadIdx.x] = 0.0;
+}
 }  // namespace
 
 // Factor the Np x Np matrix A (lower triangle, in place) and write the inverses of its diagonal tiles to winv, one launch.
@@ -920,8 +926,10 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   p.A = A; p.lda = lda; p.strideA = sA;
   p.winv = winv; p.strideW = sW;
   p.wt = wt; p.strideWt = wt ? gpk_bstride(h, wt) : 0;
-  // (the tasks of W^T read whole tiles of it, the diagonal ones included, whose lower blocks nobody writes: zeros)
-  if (wt) GPK_CHECK_HIP(h, hipMemsetAsync(wt, 0, (size_t)Np * lda * sizeof(double), h->stream));
+  if (wt) {
+    hipLaunchKernelGGL(zero_diag_tiles_kernel, dim3((unsigned)Np), dim3(TS), 0, h->stream, wt, (long long)lda);
+    GPK_LAUNCH_CHECK(h);
+  }
   p.info = h->d_info; p.row0 = row0;
   p.nt = nt; p.batch = nb; p.ntasks = (int)ntasks;
   p.prog = nt <= h->ptile_prog_max_nt ? 1 : 0;
