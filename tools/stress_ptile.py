@@ -71,6 +71,23 @@ def main():
                 bad += 1
                 print(f"MISMATCH fused N={n} P={P} run {r}: |dKinv| {float((Ki - ref[3]).abs().max()):.3e}", flush=True)
         print(f"fused N={n:5d} P={P}: {reps} runs bit-identical" if bad == 0 else f"fused N={n} P={P}: {bad} mismatches so far", flush=True)
+    # the same for a batch (gpk_lml_batched: three problems in the one launch while their rows together stay below the bound)
+    from unmanned_aerial_vehicles_amd import BatchedARDGP
+    for n in (640, 1000, 1500):
+        rng = np.random.default_rng(n + 1)
+        X = rng.standard_normal((n, 7))
+        Y = rng.standard_normal((n, 3))
+        bg = BatchedARDGP(length_scale=1.5 * np.ones(7), noise_level=0.1, alpha=1e-4, normalize_y=True, optimizer=None).fit(X, Y)
+        ref = None
+        for r in range(reps):
+            l, g = bg.log_marginal_likelihood(bg.thetas, eval_gradient=True, fused=True)
+            if ref is None:
+                ref = (l.copy(), g.copy())
+                assert np.isfinite(l).all() and np.isfinite(g).all()
+            elif not (np.array_equal(l, ref[0]) and np.array_equal(g, ref[1])):
+                bad += 1
+                print(f"MISMATCH fused batch N={n} run {r}", flush=True)
+        print(f"fused N={n:5d} B=3: {reps} runs bit-identical" if bad == 0 else f"fused N={n} B=3: {bad} mismatches so far", flush=True)
     print(f"{'OK' if bad == 0 else 'FAILED'}: {bad} mismatches, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 

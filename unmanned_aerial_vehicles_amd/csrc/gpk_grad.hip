@@ -206,6 +206,52 @@ extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, con
   return GPK_OK;
 }
 
+int gpk_lml_chain_batched(gpk_handle h, int B, const double* X, int64_t N, int D, const double* ls, const double* sf2,
+                          const double* noise, const double* Yn, int64_t Ne, double* K, int64_t Np, double* winv, double* W,
+                          double* T, size_t tsz, double* alpha, double* Kinv, double* terms, double* grads, int* info) {
+  GPK_REQUIRE(h, B >= 1 && B <= GPK_MAX_BATCH && h->batch == 1, "lml_batched: bad batch");
+  const size_t nn = (size_t)Np * Np;
+  GPK_TRY(gpk_batch_begin(h, B));
+  auto chain = [&]() -> int {
+    const struct { const void* p; size_t stride; } bufs[] = {
+        {K, nn * 8}, {winv, (size_t)Np * GPK_TILE * 8}, {W, nn * 8}, {T, tsz * 8}, {Yn, (size_t)Ne * 8}, {alpha, (size_t)Ne * 8},
+        {Kinv, nn * 8}};
+    for (const auto& b : bufs)
+      if (b.p) GPK_TRY(gpk_batch_buffer(h, b.p, (int64_t)b.stride));
+    // factor and inverse factor: one persistent launch for all problems when a gradient is wanted and the size allows
+    int fused = 0;
+    if (Kinv) GPK_TRY(gpk_potrf_trtri_enqueue(h, K, Np, Np, winv, W, Np, Kinv, &fused));
+    if (!fused) {
+      GPK_TRY(gpk_potrf_enqueue(h, K, Np, Np, winv));
+      GPK_TRY(gpk_trtri(h, K, Np, Np, winv, W, Np, T));
+    }
+    GPK_TRY(gpk_potrs_inv(h, W, Np, Np, Yn, N, 1, alpha));
+    if (Kinv) GPK_TRY(gpk_wtw(h, W, Np, Np, Kinv, Np));
+    // per problem: terms to d_small[4 b ..], gradient sums to d_small[64 + 32 b ..]; then everything back in one copy
+    for (int b = 0; b < B; ++b) {
+      GPK_TRY(gpk_lml_terms_enqueue(h, K + b * nn, N, Np, Yn + (size_t)b * Ne, alpha + (size_t)b * Ne, 1, h->d_small + 4 * b));
+      if (Kinv)
+        GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls + (size_t)b * D, sf2[b], alpha + (size_t)b * Ne, 1, Kinv + b * nn, Np,
+                                     h->d_small + 64 + 32 * b));
+    }
+    GPK_TRY(gpk_status_enqueue(h));
+    GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, 4096, hipMemcpyDeviceToHost, h->stream));
+    GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+    const int* hst = reinterpret_cast<const int*>(h->h_small + GPK_STATUS_OFF);
+    const int rc = gpk_potrf_finish(h, hst, info, hst[GPK_MAX_BATCH]);
+    if (rc != GPK_OK && rc != GPK_NOT_PD) return rc;          // per-problem outcome is in info[]
+    for (int b = 0; b < B; ++b) {
+      terms[2 * b] = h->h_small[4 * b];
+      terms[2 * b + 1] = h->h_small[4 * b + 1];
+      if (Kinv) grad_from_sums(h->h_small + 64 + 32 * b, D, noise[b], grads + (size_t)b * (D + 2));
+    }
+    return GPK_OK;
+  };
+  const int rc = chain();
+  (void)gpk_batch_end(h);
+  return rc;
+}
+
 // One evaluation of the log-marginal likelihood (and its gradient) as ONE chain of launches with ONE synchronisation: what the
 // estimator's optimiser loop runs per trial theta.  At the reference's own size (N = 1000) the three host round trips of the
 // call-by-call route - the pivot check of gpk_potrf, gpk_lml_terms, gpk_lml_grad - are a seventh of an evaluation.
@@ -233,11 +279,12 @@ extern "C" int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, con
     GPK_TRY(gpk_wtw(h, W, Np, Np, Kinv, Np));
     GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls, sf2, alpha, P, Kinv, Np, dgrad));
   }
-  int hinfo[GPK_MAX_BATCH] = {0};
-  GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, (64 + GW) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  GPK_CHECK_HIP(h, hipMemcpyAsync(hinfo, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  // ONE copy to pinned memory: terms, gradient sums, the pivot failure and the one-launch factorisation's flag
+  GPK_TRY(gpk_status_enqueue(h));
+  GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, 4096, hipMemcpyDeviceToHost, h->stream));
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-  GPK_TRY(gpk_potrf_finish(h, hinfo, info));      // GPK_NOT_PD: what follows the factorisation ran on a finite, meaningless factor
+  const int* hst = reinterpret_cast<const int*>(h->h_small + GPK_STATUS_OFF);
+  GPK_TRY(gpk_potrf_finish(h, hst, info, hst[GPK_MAX_BATCH]));   // GPK_NOT_PD: what follows the factorisation ran on a finite, meaningless factor
   for (int i = 0; i < 1 + P; ++i) terms[i] = h->h_small[i];
   if (grad) grad_from_sums(h->h_small + 64, D, noise, grad);
   return GPK_OK;

@@ -113,17 +113,27 @@ constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 4 * 8 * 512;   // t
                                                         // tile / of the tile left of it / of the tile left of that one published so far
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
 int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt = nullptr);
-int gpk_potrf_ptile_check(gpk_handle h);
+int gpk_potrf_ptile_check(gpk_handle h, int gave_up = -1);
 void gpk_model_free(gpk_handle h);   // gpk_model.hip
 // the launches of gpk_potrf / gpk_lml_terms / gpk_lml_grad without their synchronisations (gpk_lml_eval)
 int gpk_potrf_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv);
-int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info);
+int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info, int gave_up = -1);
+// the pivot failures (h->batch ints) and the one-launch factorisation's "gave up" flag to ints [0, 8] of the status words
+// h->d_small + GPK_STATUS_OFF: a caller that reads d_small back anyway needs no other copy (gpk_lml_eval, gpk_lml_batched)
+constexpr int GPK_STATUS_OFF = 480;
+int gpk_status_enqueue(gpk_handle h);
 int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, double* W, int64_t ldw, double* wt,
                             int* used);   // factor + inverse factor as one persistent launch (small matrices), or *used = 0
 int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
                           double* dout);
 int gpk_lml_grad_enqueue(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, const double* alpha,
                          int P, const double* Kinv, int64_t ldk, double* dout);
+// B single-output evaluations on shared X as ONE chain with ONE synchronisation (gpk_lml_batched): the buffers hold the B
+// problems one behind the other (K, W, Kinv: Np * Np doubles apart; winv: Np * 128; T: tsz; Yn, alpha: Ne).  K holds the
+// Gram matrices on entry.  terms[2 b .. 2 b + 1], grads[b * (D + 2) ..] (gpk_lml_grad's order), info[b] (pivot failures).
+int gpk_lml_chain_batched(gpk_handle h, int B, const double* X, int64_t N, int D, const double* ls /* B x D */, const double* sf2,
+                          const double* noise, const double* Yn, int64_t Ne, double* K, int64_t Np, double* winv, double* W,
+                          double* T, size_t tsz, double* alpha, double* Kinv, double* terms, double* grads, int* info);
 
 // Event brackets of gpk_timing (no-ops unless enabled): record the first event, launch, record the second.
 constexpr int GPK_TIMING_RING = 64;

@@ -771,24 +771,25 @@ extern "C" int gpk_lml_batched(gpk_handle h, const double* thetas, int n_theta, 
   for (int b = 0; b < B; ++b)
     GPK_TRY(gpk_gram(h, GPK_F64, m->X, m->N, D, ls[b], m->sf2[b], noise[b] + m->jitter, m->sK + (size_t)b * m->nn(), m->Np));
   int info[GPK_MAX_BATCH] = {0};
-  GPK_TRY(batched_chain(h, m, m->sK, m->swinv, m->sW, m->sT, m->salpha, grad ? m->sKinv : nullptr, info));
+  double terms[2 * GPK_MAX_BATCH], g[GPK_MAX_BATCH * (GPK_MAX_D_PREDICT + 2)], lsf[GPK_MAX_BATCH * GPK_MAX_D_PREDICT];
+  for (int b = 0; b < B; ++b)
+    for (int d = 0; d < D; ++d) lsf[b * D + d] = ls[b][d];
+  // factor, inverse factor, alpha, K^-1, terms and gradient passes of all B models: one chain, one synchronisation
+  GPK_TRY(gpk_lml_chain_batched(h, B, m->X, m->N, D, lsf, m->sf2, noise, m->Yn, m->Ne, m->sK, m->Np, m->swinv, m->sW, m->sT,
+                                m->tsz(), m->salpha, grad ? m->sKinv : nullptr, terms, g, info));
   for (int b = 0; b < B; ++b) {
     if (info[b] != 0) {              // inside an optimiser: LML = -inf, zero gradient (_gpr.py:586-589)
       lml[b] = -std::numeric_limits<double>::infinity();
       if (grad) for (int i = 0; i < n_theta; ++i) grad[b * n_theta + i] = 0.0;
       continue;
     }
-    double terms[2];
-    GPK_TRY(gpk_lml_terms(h, m->sK + (size_t)b * m->nn(), m->N, m->Np, m->Yn + (size_t)b * m->Ne, m->salpha + (size_t)b * m->Ne, 1, terms));
-    lml[b] = -0.5 * terms[1] - terms[0] - 0.5 * (double)m->N * std::log(2.0 * M_PI);
+    lml[b] = -0.5 * terms[2 * b + 1] - terms[2 * b] - 0.5 * (double)m->N * std::log(2.0 * M_PI);
     if (grad) {
-      double g[GPK_MAX_D_PREDICT + 2];
-      GPK_TRY(gpk_lml_grad(h, m->X, m->N, D, ls[b], m->sf2[b], noise[b], m->salpha + (size_t)b * m->Ne, 1,
-                           m->sKinv + (size_t)b * m->nn(), m->Np, g));
+      const double* gs = g + (size_t)b * (D + 2);
       double* gb = grad + (size_t)b * n_theta;
-      if (nl == 1) { double s = 0.0; for (int d = 0; d < D; ++d) s += g[d]; gb[0] = s; }   // kernels.py:1574-1576
-      else for (int d = 0; d < D; ++d) gb[d] = g[d];
-      gb[nl] = g[D];
+      if (nl == 1) { double s = 0.0; for (int d = 0; d < D; ++d) s += gs[d]; gb[0] = s; }   // kernels.py:1574-1576
+      else for (int d = 0; d < D; ++d) gb[d] = gs[d];
+      gb[nl] = gs[D];
     }
   }
   return GPK_OK;

@@ -888,7 +888,8 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
 
 // the diagonal tiles of W^T zeroed: the tasks of W^T read whole tiles, the diagonal task writes only the blocks on and
 // right of a diagonal tile's block diagonal
-__global__ void zero_diag_tiles_kernel(double* __restrict__ Wt, long long ldt) {
+__global__ void zero_diag_tiles_kernel(double* __restrict__ Wt0, long long ldt, long long strideWt) {
+  double* __restrict__ Wt = reinterpret_cast<double*>(reinterpret_cast<char*>(Wt0) + blockIdx.y * strideWt);
   const long long r = blockIdx.x;
   Wt[r * ldt + (r / TS) * TS + threadIdx.x] = 0.0;
 }
@@ -927,7 +928,7 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   p.winv = winv; p.strideW = sW;
   p.wt = wt; p.strideWt = wt ? gpk_bstride(h, wt) : 0;
   if (wt) {
-    hipLaunchKernelGGL(zero_diag_tiles_kernel, dim3((unsigned)Np), dim3(TS), 0, h->stream, wt, (long long)lda);
+    hipLaunchKernelGGL(zero_diag_tiles_kernel, dim3((unsigned)Np, (unsigned)nb), dim3(TS), 0, h->stream, wt, (long long)lda, p.strideWt);
     GPK_LAUNCH_CHECK(h);
   }
   p.info = h->d_info; p.row0 = row0;
@@ -953,7 +954,7 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
 }
 
 // after the stream has been synchronised: did the launch give up?
-int gpk_potrf_ptile_check(gpk_handle h) {
+int gpk_potrf_ptile_check(gpk_handle h, int gave_up) {
   if (!h->ptile_trace_path.empty() && h->scratch) {
     std::vector<long long> t((size_t)h->ptile_trace_n * 16 + 64);
     GPK_CHECK_HIP(h, hipMemcpy(t.data(), h->scratch, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
@@ -970,8 +971,8 @@ int gpk_potrf_ptile_check(gpk_handle h) {
     }
     h->ptile_trace_path.clear();
   }
-  int ab = 0;
-  GPK_CHECK_HIP(h, hipMemcpy(&ab, h->d_ptile + GPK_PTILE_CTRL_INTS, sizeof(int), hipMemcpyDeviceToHost));
+  int ab = gave_up;            // (>= 0: the caller read the flag back with its own results, gpk_status_enqueue)
+  if (ab < 0) GPK_CHECK_HIP(h, hipMemcpy(&ab, h->d_ptile + GPK_PTILE_CTRL_INTS, sizeof(int), hipMemcpyDeviceToHost));
   if (ab != 0) {
     h->err = "potrf: the one-launch factorisation timed out waiting for a tile (internal error)";
     return GPK_HIP_ERROR;
