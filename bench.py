@@ -734,7 +734,7 @@ def main():
                                  "inverse": "explicit inverse factor W = L^-1 (N^3/3 flops, fp64 MFMA) + fp32 copy",
                                  "solve": "fp32 copy of L"}[method],
                "variance_prep_s": prep_s, "trtri_s": trtri_s,
-               "variance_split_ms": ((prep_s - trtri_s) * 1e3) if trtri_s else None,    # block maxima + split: two passes over W
+               "variance_split_ms": ((prep_s - trtri_s) * 1e3) if trtri_s else None,    # the split: ONE pass over W (the block maxima come out of the inverse factor's product epilogues)
                "trtri_GFLOPs": (N ** 3 / 3.0 / trtri_s / 1e9) if trtri_s else None,
                "replicated_per_rank": world > 1}
         return dev, fit

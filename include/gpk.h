@@ -260,6 +260,10 @@ GPK_API int gpk_split2_rows(gpk_handle h, const float* W, int64_t n, int64_t ld,
  * on the lower tiles while the fp32 copy (17 GB at N = 65 536) and two passes over it are gone; the 16-column blocks right of
  * a row's diagonal tile - which the variance launch never reads - are left unwritten.                                    */
 GPK_API int gpk_split2_rows_f64(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst);
+/* gpk_split2_rows_f64_absmax: the same with the first pass over W done already: on entry scales[n / 128] holds max |(float)W_ij|
+ * over the lower triangle of each 128-row block - what gpk_trtri_absmax leaves behind - and the call turns it into the scales
+ * and writes the parts: ONE pass over W (read 8, write 4 bytes per lower-tile entry) instead of two.  Same bits.             */
+GPK_API int gpk_split2_rows_f64_absmax(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst);
 GPK_API int gpk_predict_var_inv_split2(gpk_handle h, const float* X, int64_t N, int D, const double* ls, double sf2,
                                        const void* W2, const float* w_scales, int64_t Np, const float* Xq, int64_t M,
                                        double kss, double floor_, void* work2, double* var);
@@ -317,6 +321,11 @@ GPK_API int gpk_predict_var(gpk_handle h, int dtype, const void* X, int64_t N, i
  * with solve_triangular(L, K*^T) evaluated as (L^-1) K*^T.                                          */
 GPK_API int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
               int64_t ldw, double* work);
+/* gpk_trtri_absmax: gpk_trtri that also leaves block_absmax[Np / 128] (dev) = max |(float)W_ij| over the lower triangle of each
+ * 128-row block, accumulated as the tiles of W are written (the epilogue of the level products; no pass over W): the first
+ * half of gpk_split2_rows_f64, for gpk_split2_rows_f64_absmax.  Not in batched mode.                                        */
+GPK_API int gpk_trtri_absmax(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
+              int64_t ldw, double* work, float* block_absmax);
 GPK_API int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_t lda, float* Af, int64_t ldaf);
 GPK_API int gpk_predict_var_inv(gpk_handle h, int dtype, const void* X, int64_t N, int D, const double* ls,
                         double sf2, const void* W, int64_t Np, int64_t ldw, const void* Xq, int64_t M,

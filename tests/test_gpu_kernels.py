@@ -557,6 +557,56 @@ def test_split2_rows_layout_and_scales(be):
     assert np.all(np.abs(tot - want)[low] <= np.maximum(2.0 ** -23 * np.abs(want)[low], 2.0 ** -25))
 
 
+@pytest.mark.parametrize("N", [100, 250, 1000, 2300, 4096, 10000])
+def test_trtri_absmax_feeds_the_split_bit_identically(be, N):
+    """gpk_trtri_absmax accumulates max |(float)W_ij| per 128-row block while the tiles of W are written (the epilogue of the
+    level products + the diagonal tiles), and gpk_split2_rows_f64_absmax splits with it in ONE pass over W: the same W, block
+    maxima, scales and fp16 parts, bit for bit, as gpk_trtri followed by the two-pass gpk_split2_rows_f64 - for one tile, ragged
+    tile counts (N = 2300: 18 tiles; 10 000: 79) and with the depth-first form of gpk_trtri (its fall-back pass)."""
+    import torch
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(N)
+    X = rng.standard_normal((N, 6))
+    dev = DeviceGP(X, rng.standard_normal((N, 1)), be)
+    dev.factorize(1.3, 1.0, 0.0301)
+    Np = dev.Np
+    work = be.empty(((Np // 2 + 128) ** 2,), torch.float64)
+
+    def run(absmax_route):
+        W = torch.full((Np, Np), float("nan"), dtype=torch.float64, device=be.device)
+        sc = torch.full((Np // 128,), float("nan"), dtype=torch.float32, device=be.device)
+        dst = torch.zeros((Np * Np * 4,), dtype=torch.uint8, device=be.device)
+        be.bind_stream()
+        if absmax_route:
+            be.check(be.lib.gpk_trtri_absmax(be.h, _p(dev.K), Np, Np, _p(dev.winv), _p(W), Np, _p(work), _p(sc)))
+            amax = sc.clone()
+            be.check(be.lib.gpk_split2_rows_f64_absmax(be.h, _p(W), Np, Np, _p(sc), _p(dst)))
+        else:
+            be.check(be.lib.gpk_trtri(be.h, _p(dev.K), Np, Np, _p(dev.winv), _p(W), Np, _p(work)))
+            amax = torch.stack([torch.tril(W)[128 * b:128 * b + 128].float().abs().max() for b in range(Np // 128)])
+            be.check(be.lib.gpk_split2_rows_f64(be.h, _p(W), Np, Np, _p(sc), _p(dst)))
+        return torch.tril(W), amax, sc, dst
+
+    W0, a0, s0, d0 = run(False)
+    W1, a1, s1, d1 = run(True)
+    assert torch.equal(W0, W1) and torch.equal(a0, a1) and torch.equal(s0, s1)
+    # the parts: every 16-column block up to a row's diagonal tile is written by both
+    KB = Np // 16
+    v0 = d0.view(torch.int32).view(Np // 32, KB, 2, 64, 4)
+    v1 = d1.view(torch.int32).view(Np // 32, KB, 2, 64, 4)
+    for rb in range(0, Np // 32, max(1, Np // 32 // 9)):
+        kmax = ((rb * 32) // 128 + 1) * 8
+        assert torch.equal(v0[rb, :kmax], v1[rb, :kmax])
+    if Np >= 256:
+        be.check(be.lib.gpk_set_option(be.h, b"trtri_levels", 0))
+        try:
+            W2, a2, s2, d2 = run(True)
+        finally:
+            be.check(be.lib.gpk_set_option(be.h, b"trtri_levels", 1))
+        # (the depth-first form sums in another order: its own W, and the maxima of THAT W)
+        assert torch.equal(a2, torch.stack([W2[128 * b:128 * b + 128].float().abs().max() for b in range(Np // 128)]))
+
+
 @pytest.mark.parametrize("N,M", [(3000, 700), (5000, 130), (2500, 1000), (3300, 300), (8192, 4200), (4096, 16000)])
 def test_variance_16bit_split_paths(be, N, M):
     """K5 on the 16-bit matrix pipe against the fp64 path and the exact-fp32 MFMA path on the same queries: the bf16 x 3

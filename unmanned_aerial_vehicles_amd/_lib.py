@@ -40,6 +40,7 @@ SIGNATURES = {
     "gpk_model_release": (_int, [_vp]),
     "gpk_split2_rows": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gpk_split2_rows_f64": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "gpk_split2_rows_f64_absmax": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "gpk_predict_var_inv_split2": (_int, [_vp, _vp, _i64, _int, _dp, _dbl, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _vp, _vp]),
     "gpk_predict_mean_var_split2": (_int, [_vp, _vp, _vp, _i64, _int, _int, _dp, _dbl, _dp, _dp, _dp, _vp, _vp, _i64, _vp, _i64,
                                            _dbl, _dbl, _vp, _vp, _dbl, _vp, _vp]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "gpk_predict_var": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _vp, _i64, _dbl,
                                _dbl, _vp, _vp]),
     "gpk_trtri": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "gpk_trtri_absmax": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "gpk_tril_to_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "gpk_predict_var_inv": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _vp, _i64, _i64, _vp, _i64, _dbl, _dbl,
                                    _vp, _vp]),

@@ -681,9 +681,28 @@ int trtri_rec(gpk_handle h, const double* L, int64_t ldl, int64_t n, const doubl
 // (N = 4096: 11 instead of 94), at most twice that otherwise (N = 10 000, 79 tiles: 23 instead of 158).  With the
 // handle in batched mode every launch covers all problems of the batch.
 // T: scratch of at least (Np / 2 + 128)^2 doubles (per problem); a launch lays it out with its own leading dimension.
+// max |(float)w_ij| over the lower triangle of the diagonal tiles (the tile inverses), per tile: the part of a 128-row
+// block's maximum that no product writes
+__global__ __launch_bounds__(256) void leaf_absmax_kernel(const double* __restrict__ winv, unsigned* __restrict__ out) {
+  const double* w = winv + (long long)blockIdx.x * NB * NB;
+  float m = 0.f;
+  for (int e = threadIdx.x; e < NB * NB; e += 256)
+    if ((e & 127) <= (e >> 7)) m = fmaxf(m, fabsf((float)w[e]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out + blockIdx.x, __float_as_uint(m));
+}
+
+// amax != nullptr (one problem only): max |(float)W_ij| per 128-row block of the lower triangle is accumulated there as the
+// tiles are written (the products' epilogue; the diagonal tiles by leaf_absmax_kernel) - the first pass of
+// gpk_split2_rows_f64 without reading W again
 int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const double* winv, double* W, int64_t ldw,
-                 double* T) {
+                 double* T, unsigned* amax = nullptr) {
   const int64_t nl = Np / NB;
+  if (amax) {
+    GPK_CHECK_HIP(h, hipMemsetAsync(amax, 0, nl * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(leaf_absmax_kernel, dim3((unsigned)nl), dim3(256), 0, h->stream, winv, amax);
+    GPK_LAUNCH_CHECK(h);
+  }
   hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, (unsigned)nl, (unsigned)h->batch), dim3(256), 0, h->stream, winv, W,
                      (long long)ldw, (long long)(NB * NB * sizeof(double)), (long long)(NB * (ldw + 1) * sizeof(double)),
                      gpk_bstride(h, winv), gpk_bstride(h, W));
@@ -710,6 +729,7 @@ int trtri_levels(gpk_handle h, const double* L, int64_t ldl, int64_t Np, const d
     g2.sA = (long long)(n * (ldw + 1) * sizeof(double));
     g2.sB = (long long)(h2 * sizeof(double));
     g2.sC = (long long)(n * (ldw + 1) * sizeof(double));
+    if (amax) { g2.epilogue = 2; g2.amax = amax; g2.amax_base = W; }
     return gpk_gemm(h, GPK_F64, g2);
   };
   for (int64_t n = 2 * NB; n / 2 < Np; n *= 2) {
@@ -938,9 +958,25 @@ __global__ void zero_band_kernel(double* __restrict__ W0, long long Np, long lon
 }
 }  // namespace
 
+static int trtri_impl(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W, int64_t ldw,
+                      double* work, unsigned* amax);
+
 extern "C" int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
                          int64_t ldw, double* work) {
   if (!h) return GPK_BAD_ARG;
+  return trtri_impl(h, L, Np, ldl, winv, W, ldw, work, nullptr);
+}
+
+extern "C" int gpk_trtri_absmax(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W,
+                                int64_t ldw, double* work, float* block_absmax) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, block_absmax, "trtri_absmax: null pointer");
+  GPK_REQUIRE(h, h->batch == 1, "trtri_absmax: not available in batched mode");
+  return trtri_impl(h, L, Np, ldl, winv, W, ldw, work, reinterpret_cast<unsigned*>(block_absmax));
+}
+
+static int trtri_impl(gpk_handle h, const double* L, int64_t Np, int64_t ldl, const double* winv, double* W, int64_t ldw,
+                      double* work, unsigned* amax) {
   GPK_REQUIRE(h, L && winv && W && work, "trtri: null pointer");
   GPK_REQUIRE(h, Np % NB == 0 && Np > 0 && ldl >= Np && ldw >= Np, "trtri: Np must be a multiple of 128");
   if (Np > NB) {
@@ -950,8 +986,10 @@ extern "C" int gpk_trtri(gpk_handle h, const double* L, int64_t Np, int64_t ldl,
     GPK_LAUNCH_CHECK(h);
   }
   const int64_t n1 = half_split(Np);
-  if (Np >= 2 * NB && h->trtri_levels) return trtri_levels(h, L, ldl, Np, winv, W, ldw, work);
-  return trtri_rec(h, L, ldl, Np, winv, W, ldw, work, n1 > 0 ? n1 : NB);
+  if (Np >= 2 * NB && h->trtri_levels) return trtri_levels(h, L, ldl, Np, winv, W, ldw, work, amax);
+  GPK_TRY(trtri_rec(h, L, ldl, Np, winv, W, ldw, work, n1 > 0 ? n1 : NB));
+  // (the depth-first form has no epilogue for it: one pass over W)
+  return amax ? gpk_tril_block_absmax_f64_enqueue(h, W, Np, ldw, amax) : GPK_OK;
 }
 
 extern "C" int gpk_tril_to_f32(gpk_handle h, const double* A, int64_t Np, int64_t lda, float* Af, int64_t ldaf) {

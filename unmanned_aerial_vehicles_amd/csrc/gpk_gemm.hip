@@ -41,6 +41,10 @@ struct KParams {
   // balanced persistent schedule (launches whose tiles differ in k-range): bal_wg resident workgroups, bal_tiles tiles per
   // problem enumerated longest k-range first (rows or columns primary, ascending or descending), bal_ny problems
   int balanced, bal_wg, bal_tiles, bal_ny, bal_rows, bal_asc;
+  // epilogue 2: max |(float)C_ij| of what this launch stores, per 128-row block of the matrix that starts at amax_base with
+  // leading dimension ldc (C lies inside it), as the bits of a non-negative float (atomicMax)
+  unsigned* amax;
+  const char* amax_base;
 };
 
 typedef unsigned int V16 __attribute__((ext_vector_type(4)));   // one 16-byte register quad
@@ -240,6 +244,26 @@ __device__ __forceinline__ void store_acc(float* __restrict__ C, long long ldc, 
         if (be != 0.f) v += be * (*p);
         *p = v;
       }
+}
+
+// Epilogue 2: store_acc with beta = 0, returning the lane's max |(float)v| over what it stored.
+template <int AB, int NB>
+__device__ __forceinline__ float store_acc_amax(double* __restrict__ C, long long ldc, int row_g, int col_g, int lane,
+                                                const d4 (&acc)[AB][NB], double alpha) {
+  float m = 0.f;
+#pragma unroll
+  for (int a = 0; a < AB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row_g + 16 * a + (lane >> 4) + 4 * i;
+        const int col = col_g + 16 * b + (lane & 15);
+        const double v = alpha * acc[a][b][i];
+        C[(long long)row * ldc + col] = v;
+        m = fmaxf(m, fabsf((float)v));
+      }
+  return m;
 }
 
 // Epilogue 1 (column sums of squares): instead of storing the tile, store for each of its TS columns the
@@ -532,6 +556,15 @@ __global__ __launch_bounds__(WM * 128, TS == 128 ? WM : 4) void gemm_kernel(KPar
   }
   if constexpr (EPI == 0) {
     store_acc<AB, NB>(C, p.ldc, row0 + row_w, col0 + col_w, lane, acc, p.alpha, p.beta);
+  } else if constexpr (EPI == 2) {
+    if constexpr (sizeof(T) == 8) {
+      float mx = store_acc_amax<AB, NB>(C, p.ldc, row0 + row_w, col0 + col_w, lane, acc, p.alpha);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      // (a wave's rows lie in one 128-row block: tiles are 64 or 128 rows and C starts on a block boundary)
+      const long long rowabs = (reinterpret_cast<const char*>(C) - p.amax_base) / (p.ldc * 8) + row0 + row_w;
+      if (lane == 0) atomicMax(p.amax + (rowabs >> 7), __float_as_uint(mx));
+    }
   } else {
     // the k-loop ended with a barrier: the staging buffers are free for the reduction
     sumsq_acc<AB, NB, WM, TS>(lds, reinterpret_cast<double*>(C), p.ldc, tm, col0, wm, col_w, lane, tid, acc,
@@ -599,6 +632,21 @@ int launch(gpk_handle h, const GemmArgs& g) {
     }
   }
   dim3 grid((unsigned)nblocks, ny), block(WM * 128);
+  p.amax = g.amax; p.amax_base = (const char*)g.amax_base;
+  if (g.epilogue == 2) {
+    if constexpr (sizeof(T) == 8) {
+      if (g.ta || !g.tb || g.beta != 0.0 || !g.amax || !g.amax_base || h->batch != 1) {
+        h->err = "gemm: the block-maximum epilogue needs ta == 0, tb == 1, beta == 0, one problem";
+        return GPK_BAD_ARG;
+      }
+      hipLaunchKernelGGL((gemm_kernel<T, false, true, 2, WM, TS>), grid, block, 0, h->stream, p);
+      GPK_LAUNCH_CHECK(h);
+      return GPK_OK;
+    } else {
+      h->err = "gemm: the block-maximum epilogue is fp64 only";
+      return GPK_BAD_ARG;
+    }
+  }
   if (g.epilogue == 1) {
     if (g.ta) { h->err = "gemm: the sum-of-squares epilogue needs ta == 0"; return GPK_BAD_ARG; }
     if (!g.tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, 1, WM, TS>), grid, block, 0, h->stream, p);

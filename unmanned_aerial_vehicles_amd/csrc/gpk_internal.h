@@ -122,6 +122,8 @@ int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info, int gave_up 
 // h->d_small + GPK_STATUS_OFF: a caller that reads d_small back anyway needs no other copy (gpk_lml_eval, gpk_lml_batched)
 constexpr int GPK_STATUS_OFF = 480;
 int gpk_status_enqueue(gpk_handle h);
+// max |(float)W_ij| over the lower triangle per 128-row block, as float bits (first pass of gpk_split2_rows_f64)
+int gpk_tril_block_absmax_f64_enqueue(gpk_handle h, const double* W, int64_t n, int64_t ld, unsigned* out);
 int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, double* W, int64_t ldw, double* wt,
                             int* used);   // factor + inverse factor as one persistent launch (small matrices), or *used = 0
 int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
@@ -184,6 +186,9 @@ struct GemmArgs {
   int k_super;      // every row of an 8-row super-tile takes the k-range of its longest row (the operand must be
                     // zero beyond each row's own range): the 64 workgroups of a super-tile then run in lockstep
   int epilogue;   // 0: store C;  1: C (fp64, ld = ldc) [tile_row][col] = sum over the tile's rows of (alpha*acc)^2
+                  // 2: store C (beta = 0) and atomicMax |(float)C_ij| into amax[128-row block of the matrix at amax_base, ld = ldc]
+  unsigned* amax;
+  const void* amax_base;
   // nbatch > 0: that many independent products in one launch (second grid dimension), operand i at base + i * stride
   // (bytes); in the handle's batched mode every problem of the batch runs all of them.
   int nbatch;
@@ -195,7 +200,7 @@ inline GemmArgs gemm_args(const void* A, int64_t lda, int ta, const void* B, int
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.m = m; g.n = n; g.k = k; g.ta = ta; g.tb = tb; g.alpha = alpha; g.beta = beta;
   g.lower_only = 0; g.kb0 = 0; g.kb_row = 0; g.kb_col = 0; g.ke0 = -1; g.ke_row = 0; g.ke_col = 0; g.epilogue = 0; g.heavy_first = 0; g.k_super = 0;
-  g.nbatch = 0; g.sA = 0; g.sB = 0; g.sC = 0;
+  g.nbatch = 0; g.sA = 0; g.sB = 0; g.sC = 0; g.amax = nullptr; g.amax_base = nullptr;
   return g;
 }
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g);

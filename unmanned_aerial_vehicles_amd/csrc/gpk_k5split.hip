@@ -533,16 +533,19 @@ extern "C" int gpk_split2_rows(gpk_handle h, const float* W, int64_t n, int64_t 
   return GPK_OK;
 }
 
-extern "C" int gpk_split2_rows_f64(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst) {
-  if (!h) return GPK_BAD_ARG;
+int gpk_tril_block_absmax_f64_enqueue(gpk_handle h, const double* W, int64_t n, int64_t ld, unsigned* out) {
+  GPK_CHECK_HIP(h, hipMemsetAsync(out, 0, (n / 128) * sizeof(unsigned), h->stream));
+  hipLaunchKernelGGL(tril_block_absmax_f64_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, W, (long long)n, (long long)ld, out);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}
+
+static int split2_rows_f64_impl(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst, bool have_absmax) {
   GPK_REQUIRE(h, W && scales && dst, "split2_rows_f64: null pointer");
   GPK_REQUIRE(h, n >= 128 && n % 128 == 0 && ld >= n && ld % 2 == 0 && n < (1ll << 24), "split2_rows_f64: n must be a multiple of 128");
   GPK_REQUIRE(h, ((uintptr_t)W % 16) == 0 && ((uintptr_t)dst % 16) == 0, "split2_rows_f64: buffers must be 16-byte aligned");
   const int nblk = (int)(n / 128);
-  GPK_CHECK_HIP(h, hipMemsetAsync(scales, 0, nblk * sizeof(float), h->stream));
-  hipLaunchKernelGGL(tril_block_absmax_f64_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, W, (long long)n, (long long)ld,
-                     reinterpret_cast<unsigned*>(scales));
-  GPK_LAUNCH_CHECK(h);
+  if (!have_absmax) GPK_TRY(gpk_tril_block_absmax_f64_enqueue(h, W, n, ld, reinterpret_cast<unsigned*>(scales)));
   hipLaunchKernelGGL(absmax_to_scale_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, h->stream,
                      reinterpret_cast<unsigned*>(scales), nblk);
   GPK_LAUNCH_CHECK(h);
@@ -550,6 +553,16 @@ extern "C" int gpk_split2_rows_f64(gpk_handle h, const double* W, int64_t n, int
                      (long long)n, (long long)ld, (const float*)scales, (V16*)dst);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
+}
+
+extern "C" int gpk_split2_rows_f64(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst) {
+  if (!h) return GPK_BAD_ARG;
+  return split2_rows_f64_impl(h, W, n, ld, scales, dst, false);
+}
+
+extern "C" int gpk_split2_rows_f64_absmax(gpk_handle h, const double* W, int64_t n, int64_t ld, float* scales, void* dst) {
+  if (!h) return GPK_BAD_ARG;
+  return split2_rows_f64_impl(h, W, n, ld, scales, dst, true);
 }
 
 namespace {

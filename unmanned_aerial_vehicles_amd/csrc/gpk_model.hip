@@ -24,6 +24,7 @@ struct gpk_model {
   float *Xf = nullptr, *alphaf = nullptr;
   void* W3 = nullptr;            // fp16 x 2 split of W in fragment order (gpk_split2_rows) ...
   float* w_scales = nullptr;     // ... and the power of two each 128-row block was scaled by
+  float* w_absmax = nullptr;     // max |(float)W_ij| per 128-row block, left by gpk_trtri_absmax (the split's first pass)
   int f32_mean_ok = -1;          // fp32 serving gate on the mean (-1: not evaluated for the current alpha)
   // scratch of gpk_lml: a second factorisation that leaves the fitted one alone
   double *sK = nullptr, *sW = nullptr, *sKinv = nullptr, *sT = nullptr, *swinv = nullptr, *salpha = nullptr;
@@ -36,7 +37,7 @@ struct gpk_model {
 namespace {
 
 void free_all(gpk_model* m) {
-  void* ptrs[] = {m->X, m->Yn, m->K, m->winv, m->W, m->alpha, m->Xf, m->alphaf, m->W3, m->w_scales, m->sK, m->sW, m->sKinv, m->sT,
+  void* ptrs[] = {m->X, m->Yn, m->K, m->winv, m->W, m->alpha, m->Xf, m->alphaf, m->W3, m->w_scales, m->w_absmax, m->sK, m->sW, m->sKinv, m->sT,
                   m->swinv, m->salpha, m->q, m->mean, m->work, m->work3, m->q64, m->var};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -186,7 +187,12 @@ int ensure_W(gpk_handle h, gpk_model* m) {
   double* T = nullptr;
   const size_t tsz = (size_t)(m->Np / 2 + 128) * (m->Np / 2 + 128);
   GPK_CHECK_HIP(h, hipMalloc((void**)&T, tsz * sizeof(double)));
-  int rc = gpk_trtri(h, m->K, m->Np, m->Np, m->winv, m->W, m->Np, T);
+  int rc = GPK_OK;
+  if (!m->w_absmax && hipMalloc((void**)&m->w_absmax, (size_t)(m->Np / 128) * sizeof(float)) != hipSuccess) {
+    rc = GPK_HIP_ERROR;
+    h->err = "fit: out of device memory";
+  }
+  if (rc == GPK_OK) rc = gpk_trtri_absmax(h, m->K, m->Np, m->Np, m->winv, m->W, m->Np, T, m->w_absmax);
   if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
   (void)hipFree(T);
   GPK_TRY(rc);
@@ -337,7 +343,10 @@ extern "C" int gpk_predict(gpk_handle h, const void* Xq, int64_t M, void* mean, 
     int rc = (hipMalloc(&m->W3, (size_t)m->Np * m->Np * 4) == hipSuccess &&
               hipMalloc((void**)&m->w_scales, (size_t)(m->Np / 128) * sizeof(float)) == hipSuccess) ? GPK_OK : GPK_HIP_ERROR;
     if (rc != GPK_OK) h->err = "predict: out of device memory for the split inverse factor";
-    if (rc == GPK_OK) rc = gpk_split2_rows_f64(h, m->W, m->Np, m->Np, m->w_scales, m->W3);
+    // (the block maxima came out of gpk_trtri_absmax's epilogues: one pass over W)
+    if (rc == GPK_OK && hipMemcpyAsync(m->w_scales, m->w_absmax, (size_t)(m->Np / 128) * sizeof(float), hipMemcpyDeviceToDevice,
+                                       h->stream) != hipSuccess) rc = GPK_HIP_ERROR;
+    if (rc == GPK_OK) rc = gpk_split2_rows_f64_absmax(h, m->W, m->Np, m->Np, m->w_scales, m->W3);
     if (rc == GPK_OK && hipStreamSynchronize(h->stream) != hipSuccess) { rc = GPK_HIP_ERROR; h->err = "predict: split of the inverse factor failed"; }
     if (rc != GPK_OK) {
       if (m->W3) { (void)hipFree(m->W3); m->W3 = nullptr; }

@@ -478,10 +478,13 @@ class DeviceGP:
             if W is None:
                 W = be.empty((self.Np, self.Np), torch.float64)
                 work = be.empty(((self.Np // 2 + 128) ** 2,), torch.float64)
+                # (the row-block maxima the fp16 x 2 split needs come out of the products' epilogue: no pass over W for them)
+                absmax = be.empty((self.Np // 128,), torch.float32)
                 with be.lock:
                     be.bind_stream()
-                    be.check(be.lib.gpk_trtri(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(W), self.Np,
-                                              _p(work)))
+                    be.check(be.lib.gpk_trtri_absmax(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(W), self.Np,
+                                                     _p(work), _p(absmax)))
+                self._Winv["absmax"] = absmax
                 del work
             if f32:
                 Wf = be.empty((self.Np, self.Np), torch.float32)
@@ -524,9 +527,14 @@ class DeviceGP:
                     be.check(be.lib.gpk_split2_rows(be.h, _p(self._Winv["f32"]), self.Np, self.Np, _p(scales), _p(W2)))
             else:                                # straight from the fp64 inverse factor: no fp32 copy, bit-identical parts
                 W = self.inverse_factor(False)
+                absmax = self._Winv.pop("absmax", None)
                 with be.lock:
                     be.bind_stream()
-                    be.check(be.lib.gpk_split2_rows_f64(be.h, _p(W), self.Np, self.Np, _p(scales), _p(W2)))
+                    if absmax is not None:       # gpk_trtri_absmax left the block maxima: one pass over W instead of two
+                        scales = absmax
+                        be.check(be.lib.gpk_split2_rows_f64_absmax(be.h, _p(W), self.Np, self.Np, _p(scales), _p(W2)))
+                    else:
+                        be.check(be.lib.gpk_split2_rows_f64(be.h, _p(W), self.Np, self.Np, _p(scales), _p(W2)))
             self._Winv["split2"] = (W2, scales)
         return self._Winv["split2"]
 
