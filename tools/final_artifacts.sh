@@ -22,3 +22,10 @@ for cfg in "4096" "4096 batch" "1024"; do tag=$(echo $cfg | tr ' ' _); rm -rf /t
 python tools/exp_ptile_trace.py 1024 2>&1 | grep -v amdgpu > $out/ptile_trace_1024.log
 python tools/exp_ptile_trace.py 4096 2>&1 | grep -v amdgpu > $out/ptile_trace_4096.log; head -8 $out/ptile_trace_4096.log
 python -u tools/run_configs.py > $out/run_configs.log 2>&1; echo "run_configs rc=$?"
+(echo "# tools/exp_lml_host.py: one LML + gradient evaluation (wall), factor + inverse factor as one launch against factor, then level-by-level inverse (GPK_PTILE_INV_NP=0)"; for n in 1000 2048 3000 4096 5120; do python tools/exp_lml_host.py $n 2>&1 | grep N= | sed 's/$/  [one launch up to 4608 rows]/'; GPK_PTILE_INV_NP=0 python tools/exp_lml_host.py $n 2>&1 | grep N= | sed 's/$/  [level by level]/'; done) > $out/lml_fused_ab.log
+(echo "# tools/exp_c5_batch.py"; python tools/exp_c5_batch.py 4096 2>&1 | grep N=; python tools/exp_c5_batch.py 1000 2>&1 | grep N=) > $out/c5_batch.log
+(echo "# tools/exp_split_time.py 65536"; python tools/exp_split_time.py 65536 2>&1 | grep rep) > $out/split_time.log
+python tools/exp_ptile_fused_trace.py 4096 1 2>&1 | grep -v amdgpu > $out/ptile_fused_trace_4096.log
+(echo "# tools/exp_train_small.py: fit with optimiser + 1 restart, P = 6"; for n in 1000 4096; do python tools/exp_train_small.py $n 1 2>&1 | tail -1; done) > $out/train_small.log
+python tools/stress_ptile.py 100 2>&1 | grep -v amdgpu > $out/stress_ptile.log; tail -1 $out/stress_ptile.log
+python -m pytest tests -m gpu -q -rs 2>&1 | tail -6 > $out/pytest_gpu.log; tail -2 $out/pytest_gpu.log

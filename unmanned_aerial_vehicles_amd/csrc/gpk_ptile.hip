@@ -950,6 +950,8 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   GPK_LAUNCH_CHECK(h);
   ++h->ptile_launches;
   *used = 1;
+  // (the stamps live in the handle's scratch, which the next call of a chain reuses: written out here and now)
+  if (p.trace) { GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream)); GPK_TRY(gpk_potrf_ptile_check(h, 0)); }
   return GPK_OK;
 }
 
