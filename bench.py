@@ -694,6 +694,15 @@ def main():
             warm.pop(1)
             warm.append(be.empty((dev.Np * dev.Np * (6 if method == "inverse_split" else 4),), torch.uint8))
             del warm
+            if method == "inverse_split2":
+                # (and the split's two kernels once on one tile: a kernel's first launch in a process pays its lazy load,
+                # ~0.7 ms here - not part of what the split costs)
+                w1 = torch.eye(128, dtype=torch.float64, device=be.device)
+                s1 = torch.ones((1,), dtype=torch.float32, device=be.device)
+                d1 = be.empty((128 * 128 * 4,), torch.uint8)
+                be.check(be.lib.gpk_split2_rows_f64_absmax(be.h, C.c_void_p(w1.data_ptr()), 128, 128, C.c_void_p(s1.data_ptr()),
+                                                           C.c_void_p(d1.data_ptr())))
+                del w1, s1, d1
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         trtri_s = None
