@@ -778,6 +778,7 @@ int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, do
   // 5.27 with the level products - the bound is on the rows of the whole batch)
   if (!wt || Np * h->batch > h->ptile_inv_max_np || ldw != lda || ((uintptr_t)wt % 128) != 0 || (gpk_bstride(h, wt) % 128) != 0)
     return GPK_OK;
+  if (h->batch > 1 && (gpk_bstride(h, wt) == 0 || gpk_bstride(h, W) == 0)) return GPK_OK;   // (every problem needs its own W^T and W)
   GPK_REQUIRE(h, A && winv && W, "potrf: null pointer");
   GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, h->batch * sizeof(int), h->stream));
   gpk_time_begin(h, GPK_TIMED_POTRF);
