@@ -746,12 +746,24 @@ namespace {
 __global__ void zero_band_kernel(double* __restrict__ W0, long long Np, long long ldw, long long strideW);   // (defined with gpk_trtri)
 // W (lower tiles, strictly below the block diagonal) from W^T (upper tiles): 64 x 64 pieces transposed through LDS
 __global__ __launch_bounds__(256) void mirror_lower_kernel(const double* __restrict__ Wt0, long long ldt, double* __restrict__ W0,
-                                                           long long ldw, int nt, long long strideWt, long long strideW) {
+                                                           long long ldw, int nt, long long strideWt, long long strideW,
+                                                           const double* __restrict__ winv0, long long strideWinv) {
   __shared__ double t[64][65];
   const double* __restrict__ Wt = reinterpret_cast<const double*>(reinterpret_cast<const char*>(Wt0) + blockIdx.y * strideWt);
   double* __restrict__ W = reinterpret_cast<double*>(reinterpret_cast<char*>(W0) + blockIdx.y * strideW);
-  // blockIdx.x: piece (a, b), a, b in 0..1, of tile pair p = (i, j), i > j, enumerated row by row
+  // blockIdx.x: piece (a, b), a, b in 0..1, of tile pair p = (i, j), i > j, enumerated row by row; behind them the four pieces
+  // of every diagonal tile, copied as they are from the tile inverses (copy_leaf_kernel's job, in the same launch)
   const int piece = blockIdx.x & 3, pr = blockIdx.x >> 2;
+  const int npair = nt * (nt - 1) / 2;
+  if (pr >= npair) {
+    const int d = pr - npair, a = piece >> 1, b = piece & 1;
+    if (d >= nt) return;
+    const double* w = reinterpret_cast<const double*>(reinterpret_cast<const char*>(winv0) + blockIdx.y * strideWinv) + (long long)d * 128 * 128;
+    double* dst = W + ((long long)(128 * d + 64 * a)) * ldw + 128 * d + 64 * b;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    for (int r = r0; r < 64; r += 4) dst[(long long)r * ldw + c] = w[(64 * a + r) * 128 + 64 * b + c];
+    return;
+  }
   int i = (int)((1.0f + __builtin_sqrtf(8.0f * (float)pr + 1.0f)) * 0.5f);
   while (i * (i - 1) / 2 > pr) --i;
   while ((i + 1) * i / 2 <= pr) ++i;
@@ -780,29 +792,19 @@ int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, do
     return GPK_OK;
   if (h->batch > 1 && (gpk_bstride(h, wt) == 0 || gpk_bstride(h, W) == 0)) return GPK_OK;   // (every problem needs its own W^T and W)
   GPK_REQUIRE(h, A && winv && W, "potrf: null pointer");
-  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_info, 0, h->batch * sizeof(int), h->stream));
   gpk_time_begin(h, GPK_TIMED_POTRF);
   h->ptile_launches = 0;
-  const int rc = gpk_potrf_ptile(h, A, Np, lda, winv, 0, used, wt);
+  // (the launch's own preparation also zeroes the pivot words and the band right of W's diagonal tiles: one launch for what were
+  // three memsets and two kernels)
+  const int rc = gpk_potrf_ptile(h, A, Np, lda, winv, 0, used, wt, W, ldw, 1);
   gpk_time_end(h);
   GPK_TRY(rc);
   if (!*used) return GPK_OK;
   const int64_t nl = Np / NB;
-  // the diagonal tiles of W from the tile inverses, zeros right of them (what the lockstep launches read), the rest mirrored
-  const unsigned ny = (unsigned)(((GPK_ZERO_BAND_TILES - 1) * NB + 255) / 256);
-  const unsigned nb = (unsigned)h->batch;
-  hipLaunchKernelGGL(zero_band_kernel, dim3((unsigned)Np, ny, nb), dim3(256), 0, h->stream, W, (long long)Np, (long long)ldw,
-                     gpk_bstride(h, W));
+  // the diagonal tiles of W from the tile inverses, the rest mirrored: one launch
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((nl * (nl - 1) / 2 + nl) * 4), (unsigned)h->batch), dim3(256), 0, h->stream,
+                     wt, (long long)lda, W, (long long)ldw, (int)nl, gpk_bstride(h, wt), gpk_bstride(h, W), winv, gpk_bstride(h, winv));
   GPK_LAUNCH_CHECK(h);
-  hipLaunchKernelGGL(copy_leaf_kernel, dim3(NB * NB / 256, (unsigned)nl, nb), dim3(256), 0, h->stream, winv, W, (long long)ldw,
-                     (long long)(NB * NB * sizeof(double)), (long long)(NB * (ldw + 1) * sizeof(double)), gpk_bstride(h, winv),
-                     gpk_bstride(h, W));
-  GPK_LAUNCH_CHECK(h);
-  if (nl > 1) {
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)(nl * (nl - 1) / 2 * 4), nb), dim3(256), 0, h->stream, wt, (long long)lda,
-                       W, (long long)ldw, (int)nl, gpk_bstride(h, wt), gpk_bstride(h, W));
-    GPK_LAUNCH_CHECK(h);
-  }
   return GPK_OK;
 }
 

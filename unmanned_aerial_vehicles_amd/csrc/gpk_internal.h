@@ -112,7 +112,10 @@ constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 4 * 8 * 512;   // t
                                                         // counters; one pause word per CU; per tile row: 16-column steps of the diagonal
                                                         // tile / of the tile left of it / of the tile left of that one published so far
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served
-int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt = nullptr);
+// wband / ldw (optional): the band of zeros right of the diagonal tiles of this matrix is written by the launch's own preparation
+// (gpk_trtri's zero_band_kernel, for the caller that goes on to the inverse factor); zero_info: so are the pivot words
+int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt = nullptr,
+                    double* wband = nullptr, int64_t ldw = 0, int zero_info = 0);
 int gpk_potrf_ptile_check(gpk_handle h, int gave_up = -1);
 void gpk_model_free(gpk_handle h);   // gpk_model.hip
 // the launches of gpk_potrf / gpk_lml_terms / gpk_lml_grad without their synchronisations (gpk_lml_eval)

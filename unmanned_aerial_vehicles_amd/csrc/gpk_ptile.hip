@@ -888,10 +888,35 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
 
 // the diagonal tiles of W^T zeroed: the tasks of W^T read whole tiles, the diagonal task writes only the blocks on and
 // right of a diagonal tile's block diagonal
-__global__ void zero_diag_tiles_kernel(double* __restrict__ Wt0, long long ldt, long long strideWt) {
-  double* __restrict__ Wt = reinterpret_cast<double*>(reinterpret_cast<char*>(Wt0) + blockIdx.y * strideWt);
-  const long long r = blockIdx.x;
-  Wt[r * ldt + (r / TS) * TS + threadIdx.x] = 0.0;
+// and, with it in ONE launch, everything else that must be zero before the kernel starts (each was a launch or a memset of its
+// own, 5 - 7 us apiece in front of a 0.3 ms factorisation): the control block, the pivot words, winv (the part above its block
+// diagonal is never written by the kernel: the tile GEMMs that use winv read whole tiles), and for the caller that goes on to
+// the inverse factor the band of zeros right of W's diagonal tiles (GPK_ZERO_BAND_TILES - 1 of them: what the lockstep
+// launches read beyond a row's own range).  Workgroup = one matrix row (of problem blockIdx.y).
+struct PrepParams {
+  int* ctrl; int nctrl;
+  int* info; int ninfo;
+  double* winv; long long strideW;
+  double* wt; long long ldt, strideWt;
+  double* wband; long long ldw, strideWb;
+  long long Np;
+};
+__global__ __launch_bounds__(256) void ptile_prepare_kernel(PrepParams p) {
+  const long long r = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (r == 0 && b == 0) {
+    for (int e = tid; e < p.nctrl; e += 256) p.ctrl[e] = 0;
+    if (tid < p.ninfo) p.info[tid] = 0;
+  }
+  if (tid < TS) {
+    reinterpret_cast<double*>(reinterpret_cast<char*>(p.winv) + b * p.strideW)[r * TS + tid] = 0.0;
+    if (p.wt) reinterpret_cast<double*>(reinterpret_cast<char*>(p.wt) + b * p.strideWt)[r * p.ldt + (r / TS) * TS + tid] = 0.0;
+  }
+  if (p.wband) {
+    double* W = reinterpret_cast<double*>(reinterpret_cast<char*>(p.wband) + b * p.strideWb);
+    const long long j0 = (r / TS + 1) * TS, j1 = min(p.Np, (r / TS + GPK_ZERO_BAND_TILES) * TS);
+    for (long long j = j0 + tid; j < j1; j += 256) W[r * p.ldw + j] = 0.0;
+  }
 }
 }  // namespace
 
@@ -899,7 +924,8 @@ __global__ void zero_diag_tiles_kernel(double* __restrict__ Wt0, long long ldt, 
 // Returns GPK_OK with *used = 0 when the shape is not served here (the caller then runs the recursion).
 // wt (optional): an Np x lda scratch that receives W^T = L^-T by tiles (upper tiles and the diagonal ones; everything else is left
 // alone) - only when the whole matrix is this one launch (row0 == 0).
-int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt) {
+int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, int row0, int* used, double* wt,
+                    double* wband, int64_t ldw, int zero_info) {
   *used = 0;
   // (three tiles and fewer stay with the launch chain - four launches: nothing to gain, and the factor keeps the bits
   // that the optimiser-path parity test of the 240-row trainer fixture was pinned with)
@@ -918,17 +944,20 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
     h->ptile_slots = 2 * (cus > 0 ? cus : 256);
   }
   const long long sA = gpk_bstride(h, A), sW = gpk_bstride(h, winv);
-  // (the word behind the control block is the sticky "some launch of this gpk_potrf gave up" flag: zeroed by the first launch)
-  GPK_CHECK_HIP(h, hipMemsetAsync(h->d_ptile, 0, (GPK_PTILE_CTRL_INTS + (h->ptile_launches == 0 ? 1 : 0)) * sizeof(int), h->stream));
-  // the part of winv above the block diagonal is never written by the kernel: the tile GEMMs that use winv read whole tiles
-  for (int b = 0; b < nb; ++b)
-    GPK_CHECK_HIP(h, hipMemsetAsync((char*)winv + b * sW, 0, (size_t)Np * TS * sizeof(double), h->stream));
   PTParams p;
   p.A = A; p.lda = lda; p.strideA = sA;
   p.winv = winv; p.strideW = sW;
   p.wt = wt; p.strideWt = wt ? gpk_bstride(h, wt) : 0;
-  if (wt) {
-    hipLaunchKernelGGL(zero_diag_tiles_kernel, dim3((unsigned)Np, (unsigned)nb), dim3(TS), 0, h->stream, wt, (long long)lda, p.strideWt);
+  {
+    PrepParams q;
+    // (the word behind the control block is the sticky "some launch of this gpk_potrf gave up" flag: zeroed by the first launch)
+    q.ctrl = h->d_ptile; q.nctrl = (int)GPK_PTILE_CTRL_INTS + (h->ptile_launches == 0 ? 1 : 0);
+    q.info = h->d_info; q.ninfo = zero_info ? nb : 0;
+    q.winv = winv; q.strideW = sW;
+    q.wt = wt; q.ldt = lda; q.strideWt = p.strideWt;
+    q.wband = wband; q.ldw = ldw; q.strideWb = wband ? gpk_bstride(h, wband) : 0;
+    q.Np = Np;
+    hipLaunchKernelGGL(ptile_prepare_kernel, dim3((unsigned)Np, (unsigned)nb), dim3(256), 0, h->stream, q);
     GPK_LAUNCH_CHECK(h);
   }
   p.info = h->d_info; p.row0 = row0;
