@@ -557,6 +557,30 @@ def test_split2_rows_layout_and_scales(be):
     assert np.all(np.abs(tot - want)[low] <= np.maximum(2.0 ** -23 * np.abs(want)[low], 2.0 ** -25))
 
 
+@pytest.mark.parametrize("N", [4500, 4700])
+def test_lml_eval_at_the_bound_of_the_fused_launch(be, N):
+    """N = 4500 (Np = 4608) is the largest size whose inverse factor rides in the one-launch factorisation, N = 4700 the first that
+    takes the level products: both against the call-by-call route (terms and factor bit-identical, gradient and alpha to
+    rounding), synthetic inputs."""
+    import torch
+    from unmanned_aerial_vehicles_amd.device import DeviceGP
+    rng = np.random.default_rng(N)
+    X = rng.standard_normal((N, 7))
+    Yn = rng.standard_normal((N, 2))
+    a = DeviceGP(X, Yn, be)
+    a.factorize(1.4, 1.1, 0.0501)
+    a.solve_alpha()
+    ld_a, quad_a = a.lml_terms()
+    g_a = a.lml_grad(0.05)
+    b = DeviceGP(X, Yn, be)
+    ld_b, quad_b, g_b = b.lml_eval(1.4, 1.1, 0.0501, 0.05, True)
+    assert ld_a == ld_b and np.array_equal(quad_a, quad_b) and torch.equal(torch.tril(a.K), torch.tril(b.K))
+    assert np.max(np.abs(g_a - g_b)) <= 1e-11 * np.max(np.abs(g_a))
+    assert float((a.alpha - b.alpha).abs().max()) <= 1e-11 * float(a.alpha.abs().max())
+    if N == 4700:
+        assert np.array_equal(g_a, g_b)          # the same level products either way
+
+
 @pytest.mark.parametrize("N", [100, 250, 1000, 2300, 4096, 10000])
 def test_trtri_absmax_feeds_the_split_bit_identically(be, N):
     """gpk_trtri_absmax accumulates max |(float)W_ij| per 128-row block while the tiles of W are written (the epilogue of the
@@ -668,7 +692,7 @@ def test_lml_gradient_kernels(be, csv_data, ka):
     assert relerr(g[:10], ka["ka6b_grad"]) < 1e-8
 
 
-@pytest.mark.parametrize("N,P,ard", [(1000, 3, False), (700, 1, True), (130, 6, False)])
+@pytest.mark.parametrize("N,P,ard", [(1000, 3, False), (700, 1, True), (130, 6, False), (400, 2, True)])
 def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
     """gpk_lml_eval - the optimiser's evaluation as one chain of launches with one synchronisation - against the same
     building blocks called one by one (three synchronisations): the factor and the terms are bit-identical (the
