@@ -574,11 +574,12 @@ def test_lml_eval_at_the_bound_of_the_fused_launch(be, N):
     g_a = a.lml_grad(0.05)
     b = DeviceGP(X, Yn, be)
     ld_b, quad_b, g_b = b.lml_eval(1.4, 1.1, 0.0501, 0.05, True)
-    assert ld_a == ld_b and np.array_equal(quad_a, quad_b) and torch.equal(torch.tril(a.K), torch.tril(b.K))
+    assert ld_a == ld_b and torch.equal(torch.tril(a.K), torch.tril(b.K))
+    assert np.allclose(quad_a, quad_b, rtol=1e-12, atol=0.0)          # y^T alpha, and alpha is W^T (W y)
     assert np.max(np.abs(g_a - g_b)) <= 1e-11 * np.max(np.abs(g_a))
     assert float((a.alpha - b.alpha).abs().max()) <= 1e-11 * float(a.alpha.abs().max())
     if N == 4700:
-        assert np.array_equal(g_a, g_b)          # the same level products either way
+        assert np.array_equal(g_a, g_b) and np.array_equal(quad_a, quad_b)      # the same level products either way
 
 
 @pytest.mark.parametrize("N", [100, 250, 1000, 2300, 4096, 10000])
@@ -695,8 +696,8 @@ def test_lml_gradient_kernels(be, csv_data, ka):
 @pytest.mark.parametrize("N,P,ard", [(1000, 3, False), (700, 1, True), (130, 6, False), (400, 2, True)])
 def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
     """gpk_lml_eval - the optimiser's evaluation as one chain of launches with one synchronisation - against the same
-    building blocks called one by one (three synchronisations): the factor and the terms are bit-identical (the
-    same tasks in the same order); alpha and the gradient are bit-identical when the inverse factor comes from the level-by-level
+    building blocks called one by one (three synchronisations): the factor and the log-determinant are bit-identical (the
+    same tasks in the same order); alpha, y^T alpha and the gradient are bit-identical when the inverse factor comes from the level-by-level
     kernels (ptile_inv_max_np=0) and agrees to rounding when its tiles are tasks of the one-launch factorisation (the
     default up to Np=4608: other summation order); K^-1 of that path against numpy; value only (no K^-1) as well; a
     non-positive-definite trial matrix raises as gpk_potrf does (sklearn/_gpr.py:586-589 turns that into -inf)."""
@@ -712,7 +713,7 @@ def test_lml_eval_one_chain_matches_call_by_call(be, csv_data, N, P, ard):
     g_a = a.lml_grad(0.1)
     b = DeviceGP(X, Yn, be)
     ld_b, quad_b, g_b = b.lml_eval(ls, 1.3, 0.1001, 0.1, True)
-    assert ld_a == ld_b and np.array_equal(quad_a, quad_b)
+    assert ld_a == ld_b and np.allclose(quad_a, quad_b, rtol=1e-12, atol=0.0)           # (y^T alpha: alpha is W^T (W y))
     assert np.max(np.abs(g_a - g_b)) <= 1e-11 * np.max(np.abs(g_a))
     assert torch.equal(torch.tril(a.K), torch.tril(b.K))
     assert float((a.alpha - b.alpha).abs().max()) <= 1e-11 * float(a.alpha.abs().max())    # alpha is W^T (W y)
