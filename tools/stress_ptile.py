@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Race hunt for the one-launch Cholesky's device-side protocol (ticket order, progress words, 16-column hand-overs): the same
 factorisation REPS times per shape - single problems and batches - every result bit-identical to the first and the launch never
-aborted; buffers poisoned with NaN before every run; then the fused factor + inverse-factor launch the same way.    python tools/stress_ptile.py [REPS]"""
+aborted; buffers poisoned with NaN before every run; then the fused factor + inverse-factor launch the same way,
+single problems, batches, and three launches at once from three host threads.    python tools/stress_ptile.py [REPS]"""
 import ctypes as C
 import os
 import sys
@@ -88,6 +89,33 @@ def main():
                 bad += 1
                 print(f"MISMATCH fused batch N={n} run {r}", flush=True)
         print(f"fused N={n:5d} B=3: {reps} runs bit-identical" if bad == 0 else f"fused N={n} B=3: {bad} mismatches so far", flush=True)
+    # three fused launches at once from three host threads on private handles and streams (how the optimiser's restarts and
+    # the per-axis models run): each thread's evaluations bit-identical to the single-threaded reference
+    from concurrent.futures import ThreadPoolExecutor
+    from unmanned_aerial_vehicles_amd.device import worker_backends
+    for n in (1000, 2048, 4096):
+        rng = np.random.default_rng(n + 7)
+        X = rng.standard_normal((n, 7))
+        Yn = rng.standard_normal((n, 2))
+        ref = DeviceGP(X, Yn, be).lml_eval(1.5, 1.0, 0.0501, 0.05, True)
+        workers = worker_backends(be.device_index, 3)
+        torch.cuda.synchronize()
+
+        def run(i):
+            wbe, stream = workers[i]
+            miss = 0
+            with torch.cuda.stream(stream):
+                dev = DeviceGP(X, Yn, wbe)
+                for r in range(max(reps // 4, 10)):
+                    ld, quad, g = dev.lml_eval(1.5, 1.0, 0.0501, 0.05, True)
+                    if not (ld == ref[0] and np.array_equal(quad, ref[1]) and np.array_equal(g, ref[2])):
+                        miss += 1
+                stream.synchronize()
+            return miss
+        with ThreadPoolExecutor(max_workers=3) as ex:
+            miss = sum(ex.map(run, range(3)))
+        bad += miss
+        print(f"fused N={n:5d} x 3 threads: {max(reps // 4, 10)} runs each bit-identical" if miss == 0 else f"fused N={n} x 3 threads: {miss} mismatches", flush=True)
     print(f"{'OK' if bad == 0 else 'FAILED'}: {bad} mismatches, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
