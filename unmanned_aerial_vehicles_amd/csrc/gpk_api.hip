@@ -40,6 +40,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   if (const char* e = getenv("GPK_PTILE_MAX_NP")) h->ptile_max_np = atoi(e);
   if (const char* e = getenv("GPK_PTILE_PROG_NT")) h->ptile_prog_max_nt = atoi(e);
   if (const char* e = getenv("GPK_PTILE_INV_NP")) h->ptile_inv_max_np = atoi(e);
+  if (const char* e = getenv("GPK_PTILE_SINGLE_NT")) h->ptile_single_max_nt = atoi(e);
   if (const char* e = getenv("GPK_PTILE_PROG_ROWS")) h->ptile_prog_rows = atoi(e) >= 2 ? 2 : 1;
   if (getenv("GPK_DEBUG_FILL")) h->debug_fill = 1;
   *out = h;
@@ -100,6 +101,7 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "ptile_max_np") h->ptile_max_np = value;
   else if (n == "ptile_prog_max_nt") h->ptile_prog_max_nt = value;
   else if (n == "ptile_inv_max_np") h->ptile_inv_max_np = value;
+  else if (n == "ptile_single_max_nt") h->ptile_single_max_nt = value;
   else if (n == "ptile_prog_rows") h->ptile_prog_rows = value >= 2 ? 2 : 1;
   else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
   return GPK_OK;

@@ -55,6 +55,7 @@ struct gpk_context {
   int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so (GPK_PTILE_PROG_ROWS)
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
+  int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU (GPK_PTILE_SINGLE_NT)
   int ptile_launches = 0;    // one-launch factorisations issued by the current gpk_potrf (their abort words are checked at its end)
   std::string ptile_trace_path;   // GPK_PTILE_TRACE (debugging aid): where the next launch's time stamps go
   long long ptile_trace_n = 0;

@@ -974,7 +974,14 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
     h->ptile_trace_path = tp;
     h->ptile_trace_n = ntasks;
   }
-  const unsigned grid = (unsigned)(ntasks < h->ptile_slots ? ntasks : h->ptile_slots);
+  // Resident workgroups: ONE per CU up to ptile_single_max_nt tile columns, two above.  A workgroup that has its CU to itself
+  // runs its task on all four matrix pipes with nobody else in its LDS and memory queues: every link of the diagonal chain is
+  // shorter, and while the chain is the bound that beats hiding latency with a second workgroup (measured, 256 against 512
+  // workgroups: N = 4096 1.21 / 1.37 ms, 5120 1.57 / 1.85, 8192 3.92 / 4.45, 10 112 6.65 / 7.10; 16 384 25.8 / 25.5: from
+  // there on the launch is throughput and two per CU win; 320 or 384 - some CUs with two - lose to both).
+  int slots = nt <= h->ptile_single_max_nt ? h->ptile_slots / 2 : h->ptile_slots;
+  if (const char* e = getenv("GPK_PTILE_SLOTS")) slots = atoi(e) > 0 ? atoi(e) : slots;      // (experiments)
+  const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
   hipLaunchKernelGGL(ptile_potrf_kernel, dim3(grid), dim3(NT), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
   ++h->ptile_launches;
