@@ -76,7 +76,8 @@ GPK_API int64_t gpk_padded(int64_t n);
  * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
  * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
  * up to this many tile columns (128 = always) the tiles under a diagonal tile follow its factorisation 16 columns at a time,
- * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 or 2 such tiles per column), "ptile_inv_max_np" (gpk_lml_eval
+ * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 or 2 such tiles per column), "ptile_single_max_nt" (up to this many tile
+ * columns (96) the launch keeps one workgroup per CU instead of two, 0 = always two), "ptile_inv_max_np" (gpk_lml_eval
  * with a gradient: up to this padded size (4608) the tiles of the inverse factor are tasks of the same launch, 0 = always the
  * level-by-level products of gpk_trtri; same values to rounding), "gemm_balanced" (tile GEMMs whose
  * tiles differ in k-range - the products with triangular operands of gpk_trtri / gpk_wtw / gpk_potrs_inv: 1 = the balanced
