@@ -173,3 +173,11 @@ def test_one_launch_handovers_on_and_off(be, n):
     finally:
         be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", 2))
     assert info2 == 0 and np.abs(np.tril(L2) - ref).max() < 1e-12 * scale
+    # two resident workgroups per CU instead of one (the launch's form above 96 tile columns): who runs a task changes, what it
+    # computes does not - the factor and the tile inverses are bit-identical
+    be.check(be.lib.gpk_set_option(be.h, b"ptile_single_max_nt", 0))
+    try:
+        _, info3, L3, W3 = potrf(be, A, 1)
+    finally:
+        be.check(be.lib.gpk_set_option(be.h, b"ptile_single_max_nt", 96))
+    assert info3 == 0 and np.array_equal(np.tril(L3), L1) and np.array_equal(W3, W1)
