@@ -137,9 +137,9 @@ __device__ int poll_ready(const int* ra, const int* rb, int need, int* abortp) {
 __device__ int poll_ktiles(const int* ready, const int* xprog, int j, int need, int* abortp) {
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
   for (int it = 0;; ++it) {
-    const int r = ld_agent(ready);
+    const int r = ld_agent(ready), x = ld_agent(xprog);      // (both loads in flight together: one latency per look, not two)
     int v = 8 * min(r, j);
-    if (r == j - 1) v += min(ld_agent(xprog), 8);
+    if (r == j - 1) v += min(x, 8);
     if (v >= need) return v;
     if ((it & 31) == 31) {
       if (ld_agent(abortp) != 0) return -1;
@@ -153,10 +153,10 @@ __device__ int poll_ktiles(const int* ready, const int* xprog, int j, int need, 
 __device__ int poll_ktiles2(const int* ra, const int* xa, const int* rb, const int* xb, int j, int need, int* abortp) {
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
   for (int it = 0;; ++it) {
-    const int a = ld_agent(ra), bq = ld_agent(rb);
+    const int a = ld_agent(ra), bq = ld_agent(rb), xav = xa ? ld_agent(xa) : 0, xbv = xb ? ld_agent(xb) : 0;
     int va = 8 * min(a, j), vb = 8 * min(bq, j);
-    if (a == j - 1 && xa) va += min(ld_agent(xa), 8);
-    if (bq == j - 1 && xb) vb += min(ld_agent(xb), 8);
+    if (a == j - 1 && xa) va += min(xav, 8);
+    if (bq == j - 1 && xb) vb += min(xbv, 8);
     const int v = min(va, vb);
     if (v >= need) return v;
     if ((it & 31) == 31) {
