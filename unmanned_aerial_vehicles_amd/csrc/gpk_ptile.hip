@@ -47,6 +47,11 @@
 // (poll_ktiles).  When a diagonal task is done, the tile under it has one fetch and one block product left, and when that
 // tile is done the next diagonal task has one k-tile left.  Deadlock freedom is unchanged: every wait is still for a task
 // earlier in the list.
+//
+// Two later additions (end of round 4): the tiles of the inverse factor's transpose W^T = L^-T as a fourth kind of task in the
+// same list (PTParams::wt: tile (i, j), i < j, = -(sum_{k=i}^{j-1} W^T(i,k) L(j,k)^T) W_jj^T - the off-diagonal task on another
+// pair of panels; they run in the part of the chip the diagonal chain leaves idle), and the residency: ONE workgroup per CU
+// up to ptile_single_max_nt tile columns (every link of the chain is shorter on a CU nobody shares), two above.
 #include <cstdlib>
 
 #include "gpk_internal.h"
