@@ -357,6 +357,16 @@ GPK_API int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, const 
                  double noise, const double* alpha, int P, const double* Kinv, int64_t ldk,
                  double* grad);
 
+/* Kernel matrix of two point sets and its length-scale derivative factor, as the package GP's kernel OBJECT hands them out:
+ * K[i][j] = sf2 exp(-r2_ij / 2), Q[i][j] = K[i][j] r2_ij, r2_ij = sum_d ((x1_id - x2_jd) / ls_d)^2 by exact differences
+ * (the reference's norm expansion, gaussian_process.py:38, differs by ~3e-14 on the flight data).  For its isotropic kernel
+ * dK/dl = Q / l and dK/dsf2 = K / sf2.  X1 dev (n1 x D), X2 dev (n2 x D), K and Q (Q may be NULL) dev (n1 x ld), ld >= n2, no
+ * padding; D <= 16.  Asynchronous on the handle's stream.
+ * Replaces: RBFKernel.__call__ / RBFKernel.gradient / GaussianProcess.compute_kernel_matrix,
+ * quadrotor_gp_mpc/quadrotor_gp_mpc/gaussian_process.py:26-60,158-171.                                              */
+GPK_API int gpk_rbf_kernel_grad(gpk_handle h, const double* X1, int64_t n1, const double* X2, int64_t n2, int D,
+                        const double* ls, double sf2, double* K, double* Q, int64_t ld);
+
 /* ---- one optimiser evaluation as one chain ------------------------------------------------------------------------
  * gpk_lml_eval: K1 (Gram of X with ls, sf2, diag_add = noise + jitter, into K), K2 (factor in place, winv), W = L^-1 (work:
  * the scratch of gpk_trtri), alpha = W^T (W Yn), the terms of gpk_lml_terms and - grad != NULL - K^-1 = W^T W (Kinv) and the

@@ -12,6 +12,9 @@ from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend  # noqa: E
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 be = get_backend(0)
+for kv in filter(None, os.environ.get("GPK_OPTS", "").split(",")):      # e.g. GPK_OPTS=ptile_xcd=0,ptile_single_max_nt=0
+    k, v = kv.split("=")
+    be.check(be.lib.gpk_set_option(be.h, k.encode(), int(v)))
 rng = np.random.default_rng(0)
 X = rng.standard_normal((N, 9))
 dev = DeviceGP(X, np.zeros((N, 1)), be)

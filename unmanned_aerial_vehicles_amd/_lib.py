@@ -55,6 +55,7 @@ SIGNATURES = {
     "gpk_gram": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _dbl, _vp, _i64]),
     "gpk_gram_rows": (_int, [_vp, _int, _vp, _i64, _int, _dp, _dbl, _dbl, _i64, _i64, _vp, _i64]),
     "gpk_cross_gram_t": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _int, _dp, _dbl, _vp, _i64]),
+    "gpk_rbf_kernel_grad": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _dp, _dbl, _vp, _vp, _i64]),
     "gpk_potrf": (_int, [_vp, _vp, _i64, _i64, _vp, C.POINTER(_int)]),
     "gpk_leaf_inverses": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gpk_factor_to_f32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),

@@ -57,6 +57,7 @@ extern "C" void gpk_destroy(gpk_handle h) {
   if (h->d_small) (void)hipFree(h->d_small);
   if (h->d_count) (void)hipFree(h->d_count);
   if (h->d_ptile) (void)hipFree(h->d_ptile);
+  if (h->d_ptile_list) (void)hipFree(h->d_ptile_list);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->serve_dev) (void)hipFree(h->serve_dev);
   if (h->serve_host) (void)hipHostFree(h->serve_host);
@@ -102,6 +103,10 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "ptile_prog_max_nt") h->ptile_prog_max_nt = value;
   else if (n == "ptile_inv_max_np") h->ptile_inv_max_np = value;
   else if (n == "ptile_single_max_nt") h->ptile_single_max_nt = value;
+  else if (n == "ptile_xcd") h->ptile_xcd = value;
+  else if (n == "ptile_grp_rows") h->ptile_grp_rows = value;
+  else if (n == "ptile_grp_cols") h->ptile_grp_cols = value;
+  else if (n == "ptile_xcd_min_nt") h->ptile_xcd_min_nt = value;
   else if (n == "ptile_prog_rows") h->ptile_prog_rows = value >= 2 ? 2 : 1;
   else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
   return GPK_OK;

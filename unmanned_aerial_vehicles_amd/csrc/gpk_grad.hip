@@ -289,3 +289,50 @@ extern "C" int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, con
   if (grad) grad_from_sums(h->h_small + 64, D, noise, grad);
   return GPK_OK;
 }
+
+
+// ---- kernel matrix and its length-scale derivative for a pair of point sets (the package kernel object's gradient) --------
+// K[i][j] = sf2 exp(-r2_ij / 2), Q[i][j] = K[i][j] r2_ij with r2_ij = sum_d ((x1_id - x2_jd) / ls_d)^2 (exact differences).
+// For the isotropic kernel of gaussian_process.py:43-60: dK/dl = K d2 / l^3 = Q / l and dK/dsf2 = K / sf2.
+// One thread per entry, 16 x 16 entries per workgroup, the two point blocks staged in LDS; an inspection call, not a hot path.
+namespace {
+__global__ __launch_bounds__(256) void rbf_kernel_grad_kernel(const double* __restrict__ X1, long long n1,
+                                                              const double* __restrict__ X2, long long n2, int D, LsG ls,
+                                                              double sf2, double* __restrict__ K, double* __restrict__ Q,
+                                                              long long ld) {
+  __shared__ double a[16][DMAXG + 1], b[16][DMAXG + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const long long i0 = (long long)blockIdx.y * 16, j0 = (long long)blockIdx.x * 16;
+  if (tx < D) {
+    a[ty][tx] = i0 + ty < n1 ? X1[(i0 + ty) * D + tx] / ls.v[tx] : 0.0;
+    b[ty][tx] = j0 + ty < n2 ? X2[(j0 + ty) * D + tx] / ls.v[tx] : 0.0;
+  }
+  __syncthreads();
+  const long long i = i0 + ty, j = j0 + tx;
+  if (i >= n1 || j >= n2) return;
+  double r2 = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double t = a[ty][d] - b[tx][d];
+    r2 = __builtin_fma(t, t, r2);
+  }
+  const double k = sf2 * exp_neg64(-0.5 * r2);
+  K[i * ld + j] = k;
+  if (Q) Q[i * ld + j] = k * r2;
+}
+}  // namespace
+
+extern "C" int gpk_rbf_kernel_grad(gpk_handle h, const double* X1, int64_t n1, const double* X2, int64_t n2, int D,
+                                   const double* ls, double sf2, double* K, double* Q, int64_t ld) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, X1 && X2 && K && ls, "rbf_kernel_grad: null pointer");
+  GPK_REQUIRE(h, n1 >= 1 && n2 >= 1 && ld >= n2, "rbf_kernel_grad: empty input or ld < n2");
+  GPK_REQUIRE(h, D >= 1 && D <= DMAXG, "rbf_kernel_grad: D must be in [1, 16]");
+  GPK_REQUIRE(h, (n1 + 15) / 16 < 65536, "rbf_kernel_grad: n1 too large");
+  LsG l{};
+  for (int d = 0; d < DMAXG; ++d) l.v[d] = d < D ? ls[d] : 1.0;
+  for (int d = 0; d < D; ++d) GPK_REQUIRE(h, ls[d] > 0.0, "rbf_kernel_grad: length scales must be positive");
+  hipLaunchKernelGGL(rbf_kernel_grad_kernel, dim3((unsigned)((n2 + 15) / 16), (unsigned)((n1 + 15) / 16)), dim3(256), 0,
+                     h->stream, X1, (long long)n1, X2, (long long)n2, D, l, sf2, K, Q, (long long)ld);
+  GPK_LAUNCH_CHECK(h);
+  return GPK_OK;
+}

@@ -56,6 +56,13 @@ struct gpk_context {
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
   int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU (GPK_PTILE_SINGLE_NT)
+  int ptile_xcd = 1;         // one task queue per XCD, tile rows dealt round-robin (0: one global ticket counter)
+  int ptile_xcd_min_nt = 56; // ... from this many tile columns up (below, the launch is bound by the diagonal chain, not by L2 traffic)
+  int ptile_grp_rows = 8, ptile_grp_cols = 4;   // ptile_xcd = 2: groups of rows x columns tiles per queue entry block
+  int* d_ptile_list = nullptr;         // the queues' task lists (device), kept for the last shape
+  size_t ptile_list_cap = 0;
+  std::vector<int> ptile_list_host;
+  long long ptile_list_key = -1;
   int ptile_launches = 0;    // one-launch factorisations issued by the current gpk_potrf (their abort words are checked at its end)
   std::string ptile_trace_path;   // GPK_PTILE_TRACE (debugging aid): where the next launch's time stamps go
   long long ptile_trace_n = 0;

@@ -100,6 +100,11 @@ struct PTParams {
                                                    // "a critical diagonal task runs on this CU" words from ctrl + PAUSE_OFF;
                                                    // progress of the diagonal tiles' factorisations from ctrl + PROG_OFF
   long long* trace;                                // GPK_PTILE_TRACE: 16 time stamps per task (100 MHz), or null
+  // XCD-aware dealing (null: ONE global ticket, tasks computed from the ticket): the task list cut into PT_QUEUES queues, each in
+  // the global (column-major) order; entry = i | j << 9 | problem << 18.  list[0 .. 8] = the queues' offsets, queue q =
+  // list[16 + off[q] .. 16 + off[q + 1]); its head is the ticket counter ctrl[QHEAD_OFF + q]; the workgroups of XCD q take from
+  // queue q (take_task below).
+  const int* list;
 };
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -225,6 +230,31 @@ __device__ __forceinline__ d4 blk_mfma(const double* ablk, const d4& b, d4 acc, 
   return acc;
 }
 
+constexpr int PT_QUEUES = 8;                  // one queue per XCD
+constexpr int QHEAD_OFF = 2;                  // ctrl ints 2 .. 9: the queues' ticket counters
+
+// One lane: the next task of this workgroup as a position in the task list, or -1 when every queue is exhausted.
+// The queues are restrictions of ONE topological order (column-major), and a task waits only for tasks earlier in that
+// order.  Workgroup b serves queue b mod 8 (`home`) while that has tasks - workgroups b and b + 8 share an XCD (observed
+// placement: round-robin; speed only), so the tasks of one tile ROW run on one XCD, whose L2 then holds the row panels they
+// share - and the other queues only once its own is exhausted (load balance at the end).
+// Liveness: let t be the earliest unfinished task, in queue q.  The tasks in front of it in q are finished, so t is at q's head
+// or already running (then everything it waits for is finished).  A workgroup whose home is q runs tasks of q only while q has
+// any - all of them earlier than t, hence finished - so it is free and takes t.  That needs ONE resident workgroup per queue:
+// the first eight of the grid (dispatched in order; the grid never exceeds what the device holds).  Should a placement ever break
+// that, the spin loops' time-out ends the launch with an error instead of a hang.
+__device__ __noinline__ int take_task(const int* list, int* ctrl, int home) {
+  int* head = ctrl + QHEAD_OFF;
+  for (int d = 0; d < PT_QUEUES; ++d) {
+    const int q = (home + d) & (PT_QUEUES - 1);
+    const int o = list[q], len = list[q + 1] - o;
+    if (d > 0 && ld_agent(head + q) >= len) continue;
+    const int t = __hip_atomic_fetch_add(head + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < len) return o + t;
+  }
+  return -1;
+}
+
 #ifdef GPK_PTILE_SUBSTAMPS   // (variant build for tools/exp_ptile_trace.py: shader-clock stamps inside step GPK_PTILE_SUBSTAMPS of D(2))
 #define PT_SUB(k) do { if (p.trace && j == 2 && JB == GPK_PTILE_SUBSTAMPS && (tl & 63) == 0) p.trace[(long long)p.ntasks * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -250,8 +280,14 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   for (;;) {
     __syncthreads();                                  // the previous task is done with LDS and with ctl
     if (tid == 0) {
-      int t = __hip_atomic_fetch_add(p.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t < p.ntasks && ld_agent(abortp) != 0) t = p.ntasks;
+      int t;
+      if (p.list) {
+        t = take_task(p.list, p.ctrl, (int)(blockIdx.x & (PT_QUEUES - 1)));
+        if (t < 0 || ld_agent(abortp) != 0) t = p.ntasks;
+      } else {
+        t = __hip_atomic_fetch_add(p.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < p.ntasks && ld_agent(abortp) != 0) t = p.ntasks;
+      }
       ctl[0] = t;
     }
     __syncthreads();
@@ -267,19 +303,24 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     // row panel j of L, both k-contiguous), its k-loop can run as soon as row j of L is final, and its closing product is
     // the same multiplication by W_jj^T.  The factorisation keeps a fifth of the matrix pipe busy at the sizes the reference
     // trains at: these tasks run in the rest.
-    const int b = task % p.batch;
-    const long long tt = task / p.batch;
-    int i, j;
-    if (p.wt) {
-      const int c = (int)(tt / nt), r = (int)(tt - (long long)c * nt);
-      j = c;
-      i = r < nt - c ? c + r : r - (nt - c);
+    int b, i, j;
+    if (p.list) {
+      const int e = p.list[16 + task];
+      i = e & 511; j = (e >> 9) & 511; b = e >> 18;
     } else {
-      j = (int)(((double)(2 * nt + 1) - __builtin_sqrt((double)(2 * nt + 1) * (2 * nt + 1) - 8.0 * (double)tt)) * 0.5);
-      j = max(0, min(j, nt - 1));
-      while (j > 0 && (long long)j * nt - (long long)j * (j - 1) / 2 > tt) --j;
-      while ((long long)(j + 1) * nt - (long long)(j + 1) * j / 2 <= tt) ++j;
-      i = j + (int)(tt - ((long long)j * nt - (long long)j * (j - 1) / 2));
+      b = task % p.batch;
+      const long long tt = task / p.batch;
+      if (p.wt) {
+        const int c = (int)(tt / nt), r = (int)(tt - (long long)c * nt);
+        j = c;
+        i = r < nt - c ? c + r : r - (nt - c);
+      } else {
+        j = (int)(((double)(2 * nt + 1) - __builtin_sqrt((double)(2 * nt + 1) * (2 * nt + 1) - 8.0 * (double)tt)) * 0.5);
+        j = max(0, min(j, nt - 1));
+        while (j > 0 && (long long)j * nt - (long long)j * (j - 1) / 2 > tt) --j;
+        while ((long long)(j + 1) * nt - (long long)(j + 1) * j / 2 <= tt) ++j;
+        i = j + (int)(tt - ((long long)j * nt - (long long)j * (j - 1) / 2));
+      }
     }
     (void)ntp;
     double* A = reinterpret_cast<double*>(reinterpret_cast<char*>(p.A) + (long long)b * p.strideA);
@@ -971,6 +1012,66 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   p.prog_rows = h->ptile_prog_rows;
   p.ctrl = h->d_ptile;
   p.trace = nullptr;
+  p.list = nullptr;
+  if (h->ptile_xcd && nt >= h->ptile_xcd_min_nt) {
+    // XCD-aware dealing: the column-major task list cut into one queue per XCD by tile ROW (row i of problem b -> queue
+    // (i + b) mod 8).  All tasks of a tile row then run on one XCD: tasks (i, j), (i, j + 1), ... share row panel i, the tasks
+    // of one tile column that meet there share row panel j, and both come from that XCD's L2 for all but the first reader.
+    // Built once per shape and kept on the handle.
+    const long long key = ((long long)nt << 32) | ((long long)h->ptile_grp_rows << 24) | ((long long)h->ptile_grp_cols << 16) |
+                          ((long long)h->ptile_xcd << 8) | ((long long)nb << 4) | (wt ? 2 : 0) | 1;
+    if (key != h->ptile_list_key) {
+      std::vector<int> q[PT_QUEUES];
+      if (h->ptile_xcd == 2 && !wt) {
+        // 2-D groups: super-columns of C tile columns; first the tasks of the diagonal super-tile (rows inside the super-column),
+        // then groups of R tile rows x C tile columns, each column-major - a topological order: T(i, j) waits for T(i, k), T(j, k),
+        // k < j, and D(j), all in earlier super-columns, in the diagonal super-tile or earlier in its own group.  A whole group goes
+        // to ONE queue: its R x C tasks read R + C row panels.
+        const int R = h->ptile_grp_rows > 0 ? h->ptile_grp_rows : 8, Cc = h->ptile_grp_cols > 0 ? h->ptile_grp_cols : 4;
+        int g = 0;
+        for (int c0 = 0; c0 < nt; c0 += Cc) {
+          const int c1 = c0 + Cc < nt ? c0 + Cc : nt;
+          for (int b = 0; b < nb; ++b) {
+            for (int c = c0; c < c1; ++c)
+              for (int i = c; i < c1; ++i) q[g % PT_QUEUES].push_back(i | (c << 9) | (b << 18));
+            ++g;
+          }
+          for (int r0 = c1; r0 < nt; r0 += R)
+            for (int b = 0; b < nb; ++b) {
+              for (int c = c0; c < c1; ++c)
+                for (int i = r0; i < r0 + R && i < nt; ++i) q[g % PT_QUEUES].push_back(i | (c << 9) | (b << 18));
+              ++g;
+            }
+        }
+      } else
+      for (int c = 0; c < nt; ++c) {
+        const int rows = wt ? nt : nt - c;
+        for (int r = 0; r < rows; ++r) {
+          const int i = r < nt - c ? c + r : r - (nt - c);
+          for (int b = 0; b < nb; ++b) q[(i + b) % PT_QUEUES].push_back(i | (c << 9) | (b << 18));
+        }
+      }
+      h->ptile_list_host.assign(16, 0);                 // [0 .. 8]: the queues' offsets
+      for (int k = 0; k < PT_QUEUES; ++k) {
+        h->ptile_list_host[k] = (int)h->ptile_list_host.size() - 16;
+        h->ptile_list_host.insert(h->ptile_list_host.end(), q[k].begin(), q[k].end());
+      }
+      h->ptile_list_host[PT_QUEUES] = (int)h->ptile_list_host.size() - 16;
+      if (h->ptile_list_host.size() > h->ptile_list_cap) {
+        GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_ptile_list) GPK_CHECK_HIP(h, hipFree(h->d_ptile_list));
+        h->d_ptile_list = nullptr; h->ptile_list_cap = 0;
+        const size_t want = (h->ptile_list_host.size() + 4095) & ~(size_t)4095;
+        GPK_CHECK_HIP(h, hipMalloc((void**)&h->d_ptile_list, want * sizeof(int)));
+        h->ptile_list_cap = want;
+      }
+      // (stream-ordered behind the launches that still read the old list; the host vector lives on the handle)
+      GPK_CHECK_HIP(h, hipMemcpyAsync(h->d_ptile_list, h->ptile_list_host.data(), h->ptile_list_host.size() * sizeof(int),
+                                      hipMemcpyHostToDevice, h->stream));
+      h->ptile_list_key = key;
+    }
+    p.list = h->d_ptile_list;
+  }
   if (const char* tp = getenv("GPK_PTILE_TRACE")) {        // debugging aid: per-task time stamps to the file named there
     void* ws = nullptr;
     GPK_TRY(gpk_scratch(h, ((size_t)ntasks * 16 + 64) * sizeof(long long), &ws));

@@ -27,11 +27,41 @@ def _block(err_nom, err_gp):
             "improvement_%": (mse_nom - mse_gp) / max(mse_nom, 1e-12) * 100.0}, se_nom, se_gp
 
 
-def evaluate_gp(gp, X_feat, R_true):
-    """gp: anything with `.predict(X) -> (N, 6)`.  The nominal model predicts zero residual."""
+def f_nominal(x, u):
+    """Double-integrator nominal model (evaluate_gp_offline.py:49-69): x = [p, v] (6,), u = [a_cmd, yaw_rate_cmd] (4,)
+    -> xdot = [v, a_cmd] (6,)."""
+    xdot = np.zeros(6, dtype=float)
+    xdot[0:3] = x[3:6]
+    xdot[3:6] = u[0:3]
+    return xdot
+
+
+def load_dataset(csv_path):
+    """(X_feat (N,10), R_true (N,6), X_state (N,6), U_ctrl (N,4)) of a dataset CSV, rows with NaN dropped - the arrays
+    `load_dataset` of evaluate_gp_offline.py:105-141 returns behind its DataFrame."""
+    from .data import read_csv
+    X, Y = read_csv(csv_path)
+    ok = ~(np.isnan(X).any(axis=1) | np.isnan(Y).any(axis=1))
+    X, Y = X[ok], Y[ok]
+    return X, Y, X[:, 0:6].copy(), X[:, 6:10].copy()
+
+
+def evaluate_gp(gp, X_feat, R_true, X_state=None, U_ctrl=None, save_prefix=None):
+    """evaluate_gp_offline.py:163-365 with its signature: gp is anything with `.predict(X) -> (N, 6)`; the nominal derivative
+    `f_nominal(X_state[i], U_ctrl[i])` is formed for every row, the true derivative reconstructed as nominal + R_true and the
+    errors taken on the derivatives, exactly as the reference does (so the table carries its roundings, not just its
+    formulas); X_state / U_ctrl default to the state and control columns of X_feat, which is what the reference's loader
+    passes.  ONE batched predict.  save_prefix (a path without suffix): writes `<prefix>_metrics.csv` and
+    `<prefix>_metrics.tex` like `:322-345`."""
     X_feat = np.asarray(X_feat, dtype=float)
     R_true = np.asarray(R_true, dtype=float)
     N = X_feat.shape[0]
+    X_state = X_feat[:, 0:6] if X_state is None else np.asarray(X_state, dtype=float)
+    U_ctrl = X_feat[:, 6:10] if U_ctrl is None else np.asarray(U_ctrl, dtype=float)
+    xdot_nom = np.zeros((N, 6), dtype=float)
+    xdot_nom[:, 0:3] = X_state[:, 3:6]          # f_nominal, row by row in the reference
+    xdot_nom[:, 3:6] = U_ctrl[:, 0:3]
+    xdot_true = xdot_nom + R_true
     R_pred = np.asarray(gp.predict(X_feat))
     if R_pred.ndim == 1:
         if R_pred.shape[0] != 6:
@@ -41,7 +71,8 @@ def evaluate_gp(gp, X_feat, R_true):
         R_pred = R_pred[:, :6]
     elif R_pred.shape[1] < 6:
         R_pred = np.hstack([R_pred, np.zeros((N, 6 - R_pred.shape[1]))])
-    err_nom, err_gp = R_true, R_true - R_pred
+    xdot_gp = xdot_nom + R_pred
+    err_nom, err_gp = xdot_true - xdot_nom, xdot_true - xdot_gp
     glob, se_nom, se_gp = _block(err_nom, err_gp)
     acc, _, _ = _block(err_nom[:, 3:6], err_gp[:, 3:6])
     imp = se_nom - se_gp
@@ -53,9 +84,25 @@ def evaluate_gp(gp, X_feat, R_true):
         table[j] = [mn, mg, np.sqrt(mn), np.sqrt(mg), (mn - mg) / max(mn, 1e-12) * 100.0,
                     r2_score(R_true[:, j], np.zeros(N)), r2_score(R_true[:, j], R_pred[:, j]),
                     np.mean(en ** 2 > eg ** 2)]
-    return {"global": glob, "acc_only": acc,
-            "fractions": {"frac_better": fb, "frac_worse": fw, "frac_equal": 1.0 - fb - fw},
-            "per_component": table, "components": COMPONENTS, "columns": COLUMNS, "pred": R_pred}
+    res = {"global": glob, "acc_only": acc,
+           "fractions": {"frac_better": fb, "frac_worse": fw, "frac_equal": 1.0 - fb - fw},
+           "per_component": table, "components": COMPONENTS, "columns": COLUMNS, "pred": R_pred}
+    if save_prefix is not None:
+        base = str(save_prefix)
+        write_metrics_csv(res, base + "_metrics.csv")
+        write_metrics_tex(res, base + "_metrics.tex")
+    return res
+
+
+def write_metrics_tex(result, path):
+    """The LaTeX table of evaluate_gp_offline.py:338-343 (`%.3e` entries)."""
+    cols = ["component"] + COLUMNS
+    with open(path, "w") as f:
+        f.write("\\begin{tabular}{l" + "r" * len(COLUMNS) + "}\n\\toprule\n")
+        f.write(" & ".join(c.replace("_", "\\_").replace("%", "\\%") for c in cols) + " \\\\\n\\midrule\n")
+        for name, row in zip(result["components"], result["per_component"]):
+            f.write(name + " & " + " & ".join("%.3e" % float(v) for v in row) + " \\\\\n")
+        f.write("\\bottomrule\n\\end{tabular}\n")
 
 
 def write_metrics_csv(result, path):

@@ -12,8 +12,7 @@ import argparse
 import os
 import pickle
 
-from .data import read_csv
-from .evaluate import evaluate_gp, write_metrics_csv
+from .evaluate import evaluate_gp, load_dataset
 from .gpr import GaussianProcessRegressor
 
 
@@ -34,10 +33,10 @@ def main(argv=None):
     ap.add_argument("--data-path", required=True)
     args = ap.parse_args(argv)
     gp = load_gp_model(args.model_path)
-    X, Y = read_csv(args.data_path)
-    res = evaluate_gp(gp, X, Y)
-    out = os.path.splitext(args.data_path)[0] + "_metrics.csv"
-    write_metrics_csv(res, out)
+    X, Y, X_state, U_ctrl = load_dataset(args.data_path)
+    prefix = os.path.splitext(args.data_path)[0]          # <csv stem>_metrics.csv / .tex, as evaluate_gp_offline.py:395-399
+    res = evaluate_gp(gp, X, Y, X_state, U_ctrl, save_prefix=prefix)
+    out = prefix + "_metrics.csv"
     g = res["global"]
     print(f"N={len(X)}  MSE nominal {g['mse_nom']:.4e} -> GP {g['mse_gp']:.4e} ({g['improvement_%']:.2f} %)  "
           f"frac better {res['fractions']['frac_better']:.3f}  -> {out}")

@@ -2,9 +2,10 @@
 
 Mirrors the non-ROS surface of `quadrotor_gp_mpc/quadrotor_gp_mpc/gaussian_process.py:63-394`
 (`add_training_data`, `fit`, `predict`, `log_marginal_likelihood`, `optimize_hyperparameters`,
-`train_gp`, `save_model`, `load_model`, attributes `kernel.length_scale`,
-`kernel.signal_variance`, `noise_variance`, `X_train`, `Y_train`, `L`, `alpha`).  The
-`rclpy.Node` base class and the topic callbacks stay in the caller: a node wraps this object.
+`train_gp`, `compute_kernel_matrix`, `training_data_callback`, `prediction_request_callback`, `save_model`,
+`load_model`, the callable `kernel` with `.gradient`, attributes `kernel.length_scale`, `kernel.signal_variance`,
+`noise_variance`, `X_train`, `Y_train`, `L`, `alpha`).  Only the `rclpy.Node` base class (publishers,
+subscriptions, the timer) stays in the caller: a node wraps this object and subscribes its two callbacks.
 
 Semantics kept from the reference: no target normalisation; K = sf2 exp(-d2 / (2 l^2)) + noise I;
 predictive variance = sf2 - |L^-1 k*|^2 (no noise term), floored at 1e-10 and tiled over the
@@ -30,11 +31,55 @@ LOG_2PI = float(np.log(2.0 * np.pi))
 
 
 class RBFKernel:
-    """Hyper-parameter holder (gaussian_process.py:19-24)."""
+    """The package's kernel object (gaussian_process.py:19-60): hyper-parameter holder AND callable.
 
-    def __init__(self, length_scale=1.0, signal_variance=1.0):
+    `kernel(X1, X2)` and `kernel.gradient(X1, X2)` run on the GPU (`gpk_rbf_kernel_grad`: one launch, squared distances by
+    exact differences - the reference's norm expansion `:38` differs from them by ~3e-14 on the flight data) and return host
+    arrays like the reference: K (n1, n2), and (dK/dlength_scale, dK/dsignal_variance) = (K d2 / l^3, K / sf2)."""
+
+    def __init__(self, length_scale=1.0, signal_variance=1.0, device=None):
         self.length_scale = length_scale
         self.signal_variance = signal_variance
+        self.device = device
+
+    def _evaluate(self, X1, X2, want_q):
+        import ctypes as C
+
+        from . import _lib
+        from .device import _torch
+        torch = _torch()
+        X1 = np.ascontiguousarray(np.atleast_2d(X1), dtype=np.float64)
+        X2 = np.ascontiguousarray(np.atleast_2d(X2), dtype=np.float64)
+        if X1.shape[1] != X2.shape[1]:
+            raise ValueError(f"feature dimensions differ: {X1.shape[1]} and {X2.shape[1]}")
+        n1, D = X1.shape
+        n2 = X2.shape[0]
+        if n1 == 0 or n2 == 0:
+            z = np.zeros((n1, n2))
+            return z, (z.copy() if want_q else None)
+        be = get_backend(self.device)
+        ls = np.full(D, float(self.length_scale))
+        with be.lock:
+            be.bind_stream()
+            a = be.upload(X1)
+            b = a if X2 is X1 else be.upload(X2)
+            K = be.empty((n1, n2), torch.float64)
+            Q = be.empty((n1, n2), torch.float64) if want_q else None
+            be.check(be.lib.gpk_rbf_kernel_grad(be.h, C.c_void_p(a.data_ptr()), n1, C.c_void_p(b.data_ptr()), n2, D,
+                                                ls.ctypes.data_as(_lib._dp), float(self.signal_variance),
+                                                C.c_void_p(K.data_ptr()), C.c_void_p(Q.data_ptr()) if want_q else None, n2))
+            Kh = K.cpu().numpy()
+            Qh = Q.cpu().numpy() if want_q else None
+        return Kh, Qh
+
+    def __call__(self, X1, X2):
+        """RBF kernel matrix (n1 x n2), gaussian_process.py:26-41."""
+        return self._evaluate(X1, X2, False)[0]
+
+    def gradient(self, X1, X2):
+        """(dK/dlength_scale, dK/dsignal_variance), gaussian_process.py:43-60."""
+        K, Q = self._evaluate(X1, X2, True)
+        return Q / float(self.length_scale), K / float(self.signal_variance)
 
 
 class _Logger:
@@ -46,7 +91,7 @@ class GaussianProcess:
     def __init__(self, input_dim=16, output_dim=12, device=None, predict_dtype="float64", logger=None):
         self.input_dim = input_dim
         self.output_dim = output_dim
-        self.kernel = RBFKernel(length_scale=1.0, signal_variance=1.0)
+        self.kernel = RBFKernel(length_scale=1.0, signal_variance=1.0, device=device)
         self.noise_variance = 0.01
         self.X_train = np.empty((0, input_dim))
         self.Y_train = np.empty((0, output_dim))
@@ -80,6 +125,16 @@ class GaussianProcess:
         self.K_inv = None
         self.L = None
         self.alpha = None
+
+    # ---- kernel matrix (gaussian_process.py:158-171) ----------------------------------------------
+    def compute_kernel_matrix(self, X1, X2=None):
+        """`kernel(X1, X2)`; with X2 omitted the training-side matrix `kernel(X1, X1) + noise_variance I` - built by `gpk_gram`,
+        the launch `fit()` factors (symmetric halves bit-identical, diagonal exactly sf2 + noise)."""
+        if X2 is not None:
+            return self.kernel(X1, X2)
+        X1 = np.atleast_2d(X1)
+        dev = DeviceGP(X1, np.zeros((len(X1), 1)), get_backend(self.device))
+        return dev.gram_host(float(self.kernel.length_scale), float(self.kernel.signal_variance), float(self.noise_variance))
 
     # ---- fit (gaussian_process.py:173-201) -----------------------------------------------------
     def _factor(self, length_scale, signal_variance, noise_variance):
@@ -192,6 +247,44 @@ class GaussianProcess:
                 self.fit()
         except Exception as e:  # noqa: BLE001
             self.get_logger().error(f"Hyperparameter optimization failed: {e}")
+
+    # ---- topic callbacks (gaussian_process.py:326-358), Node-less ------------------------------------
+    # A ROS node that wraps this object subscribes these two methods as they stand: they only touch `msg.data` (any sequence
+    # of floats - `std_msgs/Float64MultiArray` in the reference) and hand results to `prediction_pub` / `uncertainty_pub`,
+    # anything with a `publish(msg)` method (rclpy publishers; unset: the results are only returned).  `message_type` builds the
+    # outgoing message (default: a plain object with a `.data` list, so the path runs without rclpy).
+    prediction_pub = None
+    uncertainty_pub = None
+
+    class _Msg:
+        def __init__(self):
+            self.data = []
+
+    message_type = _Msg
+
+    def training_data_callback(self, msg):
+        data = np.array(msg.data, dtype=np.float64)
+        expected_size = self.input_dim + self.output_dim
+        if len(data) != expected_size:
+            self.get_logger().error(f"Invalid training data size: {len(data)} != {expected_size}")
+            return
+        self.add_training_data(data[: self.input_dim].reshape(1, -1), data[self.input_dim:].reshape(1, -1))
+
+    def prediction_request_callback(self, msg):
+        X_test = np.array(msg.data, dtype=np.float64).reshape(1, -1)
+        if X_test.shape[1] != self.input_dim:
+            self.get_logger().error(f"Invalid prediction input size: {X_test.shape[1]} != {self.input_dim}")
+            return None
+        mean, var = self.predict(X_test)
+        pred_msg = self.message_type()
+        pred_msg.data = mean.flatten().tolist()
+        unc_msg = self.message_type()
+        unc_msg.data = np.sqrt(var).flatten().tolist()
+        if self.prediction_pub is not None:
+            self.prediction_pub.publish(pred_msg)
+        if self.uncertainty_pub is not None:
+            self.uncertainty_pub.publish(unc_msg)
+        return pred_msg, unc_msg
 
     def train_gp(self):
         """Periodic training callback (gaussian_process.py:360-367)."""
