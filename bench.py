@@ -628,7 +628,7 @@ def main():
 
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
-    from unmanned_aerial_vehicles_amd.sharded import all_gather_rows
+    from unmanned_aerial_vehicles_amd.sharded import all_gather_rows, patch_low_rows
 
     be = get_backend(local_rank)
     if args.workload == "gram":
@@ -776,16 +776,51 @@ def main():
     ystd2 = torch.as_tensor(y_std ** 2, device=be.device, dtype=torch.float64)
     assert c4 or dev.fp32_mean_ok(q32), "the benchmark batch must pass the fp32 mean gate (it is served in fp32)"
 
+    ag_events = []                                 # (start, end) event pairs around every all-gather of the timed steps
+    low_patched = [0]
+    src_rank = 0 if by_broadcast else None
+    thr_low = dev.FP32_VAR_RECHECK_FRACTION * kss * float(y_std[0] ** 2)
+
+    def gathered(rows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g = all_gather_rows(rows, M * world)                                                # RCCL all-gather
+        e1.record()
+        ag_events.append((e0, e1))
+        return g
+
+    rank_queries = {rank: q32}
+
+    def queries_of(r):                             # the resident fp32 batch of rank r, regenerated from its seed (rank 0's checks)
+        if r not in rank_queries:
+            rank_queries[r] = torch.as_tensor(np.random.default_rng(1 + r).standard_normal((M, D)), dtype=torch.float32, device=be.device)
+        return rank_queries[r]
+
+    def recompute_low(rows):                       # rank 0 only (it holds the factor): fp64 variances of the gathered rows `rows`
+        q = torch.stack([queries_of(int(g) // M)[int(g) % M] for g in rows.tolist()]).double().contiguous()
+        v = dev.predict_var_dev(q, kss, 0.0, "float64", dev._fp64_var_method())
+        return v[:, None] * ystd2[None, :]
+
     def step_c4():
         mean = dev.predict_mean_dev(q32, y_mean, y_std, "float32")                 # K4 only
-        return all_gather_rows(mean, M * world) if use_dist else mean
+        return gathered(mean) if use_dist else mean
 
     def step_c3():
         # K4 + K* + K5 + finalise (un-normalise, pack [mean | var], count the rows the fp32 variance gate must recompute):
-        # libgpk launches only - the production serving path, gates included (DeviceGP.predict_packed_dev)
-        out = dev.predict_packed_dev(q32, y_mean, y_std, kss, 0.0, "float32", method)     # (M, 2P) float64
-        if use_dist:
-            out = all_gather_rows(out, M * world)                                           # RCCL all-gather
+        # libgpk launches only - the production serving path, gates included.  One rank: DeviceGP.predict_packed_dev (mean
+        # gate on the batch, variance re-check).  Several ranks: what ShardedPredictor.predict_mean_var does - the mean gate
+        # decided for ALL ranks (own shard + all-reduce MIN), the packed serving call, ONE all-gather, then the cross-rank
+        # variance gate (patch_low_rows: no collective while no row is low).
+        if not use_dist:
+            return dev.predict_packed_dev(q32, y_mean, y_std, kss, 0.0, "float32", method)  # (M, 2P) float64
+        flag = torch.tensor([1 if dev.fp32_mean_ok(q32) else 0], dtype=torch.int32, device=be.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gate = bool(int(flag.item()))
+        assert gate, "the benchmark batch must pass the fp32 mean gate on every rank"
+        out = gathered(dev.predict_packed_dev(q32, y_mean, y_std, kss, 0.0, "float32", method, True, gate))
+        if by_broadcast:
+            out, n = patch_low_rows(out, P, thr_low, recompute_low, src_rank, None)
+            low_patched[0] += n
         return out
 
     step = step_c4 if c4 else step_c3
@@ -793,6 +828,8 @@ def main():
         step()
     sync_all()
     dev.timing(True)                               # restart the event ring: it now covers exactly the timed steps
+    ag_events.clear()
+    low_patched[0] = 0
     sensors = BoardSensors(be.device.index if be.device.index is not None else 0) if rank == 0 else None
     if sensors:
         sensors.start()
@@ -809,6 +846,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(out).all()), "non-finite predictions"
+    # the collective's own share of a step: HIP events around every all-gather of the timed steps (this rank's view; the MAX
+    # over ranks is what bounds the step)
+    allgather_ms = None
+    if use_dist and ag_events:
+        mine_ms = float(np.mean([a.elapsed_time(b) for a, b in ag_events]))
+        t = torch.tensor([mine_ms], dtype=torch.float64, device=be.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allgather_ms = {"rank0_avg": mine_ms, "max_over_ranks_avg": float(t.item()), "collectives_per_step": 1,
+                        "bytes_per_rank_sent": int(out.shape[1] * M * out.element_size()),
+                        "low_variance_rows_patched": int(low_patched[0])}
 
     # ---------------------------------------------------------------- parity of the timed path (outside the timed region)
     # rank 0's own shard of the last step against the fp64 kernels on the same batch: the stated fp32 bars
@@ -829,6 +876,18 @@ def main():
             parity = {"mean_max_rel_err_vs_fp64": e_mean, "std_max_rel_err_vs_fp64": e_std, "mean_tol": 1e-4,
                       "std_tol": 1e-3, "queries_checked": M, "ok": e_mean < 1e-4 and e_std < 1e-3}
         assert parity["ok"], f"timed path disagrees with the fp64 path: {parity}"
+        if use_dist and world > 1 and not c4:
+            # one shard that ANOTHER rank served (after a broadcast: a replica without factor) against rank 0's fp64 kernels
+            q1 = queries_of(1).double()
+            theirs = out[M:2 * M].double()
+            m1 = dev.predict_mean_dev(q1, y_mean, y_std, "float64")
+            v1 = dev.predict_var_dev(q1, kss, 0.0, "float64", "inverse" if (use_w and "f64" in dev._Winv) else "solve")
+            s1 = torch.sqrt(v1[:, None] * ystd2[None, :])
+            e1m = float((theirs[:, :P] - m1).abs().max() / m1.abs().max())
+            e1s = float(((torch.sqrt(theirs[:, P:]) - s1).abs() / s1).max())
+            parity["rank1_shard"] = {"mean_max_rel_err_vs_fp64": e1m, "std_max_rel_err_vs_fp64": e1s,
+                                     "served_by": "replica (broadcast)" if by_broadcast else "refit"}
+            assert e1m < 1e-4 and e1s < 1e-3, f"rank 1's shard disagrees with the fp64 path: {parity['rank1_shard']}"
     if not c4:
         dev._Winv.pop("f64", None)                 # 34 GB back before the extras
 
@@ -1027,7 +1086,7 @@ def main():
             "peak_hbm_bytes_per_rank": int(torch.cuda.max_memory_allocated(be.device)),
             "peak_hbm_bytes_all_ranks": peak_all,
             "parity": parity,
-            "fit": fit,
+            "fit": fit, "allgather_ms": allgather_ms,
             "host_api": host_api,
             "extras": extras,
         }

@@ -56,7 +56,9 @@ struct gpk_context {
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
   int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU (GPK_PTILE_SINGLE_NT)
-  int ptile_xcd = 1;         // one task queue per XCD, tile rows dealt round-robin (0: one global ticket counter)
+  int ptile_xcd = 0;         // 1: one task queue per XCD, tile rows dealt round-robin; 2: groups of rows x columns tiles per queue; 0: ONE
+                             // global ticket counter - the default: measured, neither dealing raises the L2 hit rate (the tasks of an XCD
+                             // do not walk k in step) and both are 0-4 % slower (profiles/r05_ptile_xcd_ab.log)
   int ptile_xcd_min_nt = 56; // ... from this many tile columns up (below, the launch is bound by the diagonal chain, not by L2 traffic)
   int ptile_grp_rows = 8, ptile_grp_cols = 4;   // ptile_xcd = 2: groups of rows x columns tiles per queue entry block
   int* d_ptile_list = nullptr;         // the queues' task lists (device), kept for the last shape

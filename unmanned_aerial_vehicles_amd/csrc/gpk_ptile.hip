@@ -192,6 +192,13 @@ __device__ int poll_inv(const int* ready_i, int j, const int* wtready_j, int nee
   }
 }
 
+// one lane: a critical task lowers the pause word of its CU - only if it still holds THIS task's value: two critical tasks can
+// land on one CU (two workgroups per CU, several problems of a batch), and the later one's raise must outlive the earlier one's end
+__device__ __forceinline__ void pause_release(int* p, int tag) {
+  int expect = tag;
+  __hip_atomic_compare_exchange_strong(p, &expect, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one lane: spin until *p == 0; -1 when the launch is aborted
 __device__ int poll_clear(const int* p, int* abortp) {
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -270,7 +277,9 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
   int* abortp = p.ctrl + 1;
   // Which compute unit this workgroup runs on (XCC, shader engine / array, CU): the diagonal task - the critical path -
   // raises a word for its CU while its last k-step and its factorisation run, and the OTHER workgroup resident on that CU
-  // (two per CU) stands still meanwhile instead of taking half of the CU's matrix pipe and memory queue.
+  // (two per CU) stands still meanwhile instead of taking half of the CU's matrix pipe and memory queue.  Best effort: the key
+  // keeps 7 bits of the hardware id below the XCC (two CUs may share a word - a needless pause, never a missed dependency),
+  // and nothing makes the dispatcher place exactly one or two workgroups on every CU.
   const int cu_key = (int)((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u) * 128u +
                            ((__builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (6 << 11))) & 127u));
   int* pausep = p.ctrl + PAUSE_OFF + cu_key;
@@ -335,6 +344,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     const bool inv = i < j;                              // a tile of W^T (the output, and the own rows, are in Wt)
     double* Atile = (inv ? Wt : A) + (long long)i * TS * lda + (long long)j * TS;
     const bool diag = (i == j);
+    const int pause_tag = ((b + 1) << 16) | (j + 1);         // what a critical task of this column and problem raises on its CU
     // One body per task kind, instantiated twice: the two kinds then have their own accumulators.  (As one body with
     // run-time branches the accumulators of both k-loops meet in phi nodes and the register allocator, at its 128-register
     // limit, renames and spills them inside the loops.)
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           for (int kt = 0; kt < nkt; ++kt) {
             if (issued == kt) {                    // ring empty: k-tile kt must be final before anything moves
               // waiting for the LAST column: from here to the end of the task this workgroup is the critical path
-              if ((kt >> 3) == j - 1 && availk < nkt && tid == 0) st_agent(pausep, j + 1);
+              if ((kt >> 3) == j - 1 && availk < nkt && tid == 0) st_agent(pausep, pause_tag);
               if (!need_kt(kt + 1)) return false;
               // (stages kt .. kt + 2 are free: their last readers passed the barrier of iteration kt - 1)
               while (issued < nkt && issued < kt + 3 && issued < availk) issue(issued++);
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           __syncthreads();
           // A critical task (the diagonal task of column c, or the tile below it) runs on this CU and has raised c + 1: stand
           // still - but only a task of column >= c does, which nothing on the critical task's dependency chain waits for.
-          if (ctl[2 + cur] != 0 && j >= ctl[2 + cur] - 1 && i != j + 1) {
+          if (ctl[2 + cur] != 0 && j >= (ctl[2 + cur] & 0xffff) - 1 && i != j + 1) {
             if (tid == 0) ctl[1] = poll_clear(pausep, abortp);
             __syncthreads();
             if (ctl[1] < 0) return false;
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           //      diagonal task is done, one fetch of W_77 and one block product are left.
           // (the tile below that one does the same: the next column's critical tile needs it for its last k-step, and with
           // the whole of W_jj it would be final some 15 us later)
-          if (i == j + 1 && tid == 0) st_agent(pausep, j + 1);   // critical from here to its publication
+          if (i == j + 1 && tid == 0) st_agent(pausep, pause_tag);   // critical from here to its publication
           const double* Ljj = A + (long long)j * TS * lda + (long long)j * TS;
           const double* Wjj = Wv + (long long)j * TS * TS;
           const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ljj), 0, 0x7fffffff, 0x00020000);
@@ -672,13 +682,13 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           if (tid == 0) {
             st_agent(i == j + 1 ? xprog : yprog, 8);
             st_agent(ready + i, j + 1);
-            if (i == j + 1) st_agent(pausep, 0);
+            if (i == j + 1) pause_release(pausep, pause_tag);
           }
           PT_STAMP(5);
           return true;
         } else {
         if (tid == 0) {
-          if (i == j + 1) st_agent(pausep, j + 1);          // the tile below the diagonal: critical from here to its publication
+          if (i == j + 1) st_agent(pausep, pause_tag);          // the tile below the diagonal: critical from here to its publication
           ctl[1] = poll_ready(ready + j, nullptr, j + 1, abortp);
         }
         __syncthreads();
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         if (tid == 0) {
           if constexpr (INV) st_agent(wtready + i, j - i + 1);
           else st_agent(ready + i, j + 1);
-          if (i == j + 1) st_agent(pausep, 0);
+          if (i == j + 1) pause_release(pausep, pause_tag);
         }
         PT_STAMP(5);
         return true;
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         st_agent(wprog, 8);
         if (Wt) st_agent(wtready + j, 1);
         st_agent(ready + j, j + 1);
-        st_agent(pausep, 0);
+        pause_release(pausep, pause_tag);
       }
       PT_STAMP(10);
       if (p.trace && tid == 0) p.trace[(long long)task * 16 + 15] = (long long)__builtin_readcyclecounter();

@@ -165,7 +165,7 @@ class DeviceGP:
         self._f32 = None    # dict of fp32 copies: X, alpha [, L, winv]
         self._Winv = {}     # explicit inverse factor L^-1: {'f64': tensor} and/or {'f32': tensor}
         self._host_args = None   # predict_host: cached argument addresses
-        self._amp = self._alpha_sq = self._batch_gate = None         # fp32 mean gate: cached amplification estimate
+        self._amp = self._alpha_sq = None         # fp32 mean gate: cached amplification estimate
         self._Kinv = None
         self.replica = False     # True: a serving replica built by from_serving_state (no factor, no fp64 inverse factor)
 
@@ -236,13 +236,13 @@ class DeviceGP:
                 be.bind_stream()
                 be.check(be.lib.gpk_potrs(be.h, _p(self.K), self.Np, self.Np, _p(self.winv), _p(self.Yn), self.N,
                                           self.P, _p(self.alpha)))
-        self._amp = self._alpha_sq = self._batch_gate = None
+        self._amp = self._alpha_sq = None
         if self._f32:
             self._f32.pop("alpha", None)       # the fp32 copy of alpha is stale; X / L copies stay valid
 
     def set_alpha(self, alpha):
         self.alpha.copy_(self.be.upload(np.asarray(alpha, dtype=np.float64).reshape(self.N, self.P)))
-        self._amp = self._alpha_sq = self._batch_gate = None
+        self._amp = self._alpha_sq = None
         if self._f32:
             self._f32.pop("alpha", None)
 
@@ -306,7 +306,7 @@ class DeviceGP:
                 g.ctypes.data_as(_lib._dp) if eval_gradient else None, C.byref(info)))
         self.factored = True
         self._Winv["f64"] = W
-        self._amp = self._alpha_sq = self._batch_gate = None
+        self._amp = self._alpha_sq = None
         return terms[0], terms[1:], g
 
     def release_grad_buffers(self):
@@ -575,7 +575,7 @@ class DeviceGP:
         self._f32 = None
         self._Winv = {"split2": (tensors["W2"], tensors["w_scales"])}
         self._host_args = None
-        self._amp = self._alpha_sq = self._batch_gate = None
+        self._amp = self._alpha_sq = None
         self._Kinv = None
         self.replica = True
         return self
@@ -644,22 +644,16 @@ class DeviceGP:
         if q is None or len(q) == 0:
             return False
         M = len(q)
+        # (no cache of the batch-level answer: a new tensor that the allocator places at a freed batch's address would
+        # inherit its answer; the check is two K4 launches on <= 1024 rows, ~0.3 ms at N = 65 536 - a caller that serves ONE
+        # resident batch many times asks once and passes `mean_gate=` to the predictors)
         if isinstance(q, torch.Tensor):
-            # (the same, unmodified device tensor again - a serving loop over one resident batch: the answer stands)
-            key = (q.data_ptr(), tuple(q.shape), q.dtype, q._version, id(self._alpha_sq))
-            last = getattr(self, "_batch_gate", None)
-            if last is not None and last[0] == key:
-                return last[1]
             idx = torch.linspace(0, M - 1, min(M, self.FP32_BATCH_GATE_ROWS), device=q.device).round().long()
             qs = q[idx].to(device=self.be.device, dtype=torch.float64).contiguous()
         else:
-            key = None
             idx = np.round(np.linspace(0, M - 1, min(M, self.FP32_BATCH_GATE_ROWS))).astype(np.int64)
             qs = self.be.upload(np.ascontiguousarray(np.asarray(q, dtype=np.float64)[idx]))
-        ok = c * self.FP32_BATCH_GATE_MARGIN * self._amplification_at(qs) <= self.FP32_MEAN_TOL
-        if key is not None:
-            self._batch_gate = ((key[0], key[1], key[2], key[3], id(self._alpha_sq)), ok)
-        return ok
+        return c * self.FP32_BATCH_GATE_MARGIN * self._amplification_at(qs) <= self.FP32_MEAN_TOL
 
     def predict_var_dev(self, Xq, kss, floor=0.0, dtype="float64", method="auto"):
         """K5 on device tensors; returns a (M,) float64 tensor (normalised-target units).
@@ -749,22 +743,25 @@ class DeviceGP:
             raise RuntimeError("a serving replica holds no factor: fp64 variances are computed on the rank that fitted the model")
         return "inverse" if ("f64" in self._Winv or self.Np <= self.INVERSE_EAGER_NP) else "solve"
 
-    def _gate_mean(self, dtype, var_method, gated, q=None):
+    def _gate_mean(self, dtype, var_method, gated, q=None, mean_gate=None):
         """(predict dtype, variance method) after the mean gate: an fp32 request for a model - or, at the batch level, a
-        batch `q` - whose fp32 mean would leave the stated 1e-4 is served by the fp64 kernels."""
+        batch `q` - whose fp32 mean would leave the stated 1e-4 is served by the fp64 kernels.  mean_gate (True / False):
+        the answer of `fp32_mean_ok` as the caller already has it - the sharded predictor decides ONCE for the whole batch
+        and for every rank, a serving loop over one resident batch asks once."""
         torch = _torch()
         f32 = dtype in ("float32", np.float32, torch.float32)
-        if f32 and gated and not self.fp32_mean_ok(q):
+        if f32 and gated and not (self.fp32_mean_ok(q) if mean_gate is None else mean_gate):
             return "float64", ("auto" if var_method in ("inverse_split", "inverse_split2") else var_method)
         return ("float32" if f32 else "float64"), var_method
 
-    def predict_gated_dev(self, Xq, y_mean, y_std, kss=None, floor=0.0, dtype="float64", var_method="auto", gated=True):
+    def predict_gated_dev(self, Xq, y_mean, y_std, kss=None, floor=0.0, dtype="float64", var_method="auto", gated=True,
+                          mean_gate=None):
         """K4 (+ K5 when `kss` is given) with the fp32 serving gates applied: (mean (M, P) tensor of the dtype it was
         computed in, var (M,) float64 tensor in normalised-target units, or None).  dtype "float32" is a REQUEST: the mean gate (`fp32_mean_ok`) may
         route the model to the fp64 kernels, and single queries whose fp32 variance is below FP32_VAR_RECHECK_FRACTION of
         the prior's are recomputed by the fp64 launch.  gated=False: the raw fp32 kernels (tests, A/B timings)."""
         torch = _torch()
-        pd, vm = self._gate_mean(dtype, var_method, gated, Xq)
+        pd, vm = self._gate_mean(dtype, var_method, gated, Xq, mean_gate)
         q = self._as_queries(Xq, torch.float32 if pd == "float32" else torch.float64)
         mean = self.predict_mean_dev(q, y_mean, y_std, pd)
         if kss is None:
@@ -776,14 +773,15 @@ class DeviceGP:
                 var[low] = self.predict_var_dev(self._rows64(Xq, q, low), kss, floor, "float64", self._fp64_var_method())
         return mean, var
 
-    def predict_packed_dev(self, Xq, y_mean, y_std, kss, floor=0.0, dtype="float32", var_method="auto", gated=True):
+    def predict_packed_dev(self, Xq, y_mean, y_std, kss, floor=0.0, dtype="float32", var_method="auto", gated=True,
+                           mean_gate=None):
         """One serving step, the whole result in one (M, 2P) float64 device tensor: row m = [mean_m | var_m y_std^2]
         (un-normalised: what the all-gather of a sharded batch moves).  The fp32 default is ONE C call per panel
         (gpk_predict_mean_var_split2: K4, K* in split form, the variance launch, a finalising kernel that un-normalises,
         packs and counts the rows the variance gate must recompute); no torch arithmetic runs unless that count is
         non-zero.  Other dtypes / methods: the separate launches and gpk_pack_mean_var."""
         torch = _torch()
-        pd, vm = self._gate_mean(dtype, var_method, gated, Xq)
+        pd, vm = self._gate_mean(dtype, var_method, gated, Xq, mean_gate)
         f32 = pd == "float32"
         if vm == "auto":
             vm = "inverse_split2" if f32 else "inverse"

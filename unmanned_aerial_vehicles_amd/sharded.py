@@ -165,8 +165,9 @@ class _ReplicaModel:
 class ShardedPredictor:
     """Query-sharded posterior mean (+ variance) for a fitted `GaussianProcessRegressor`.  dtype "float32" (the default)
     is served through the gated predictors of `DeviceGP` (`predict_gated_dev` / `predict_packed_dev`): a model whose fp32
-    mean would leave the stated 1e-4 runs on the fp64 kernels on every rank (the gate is a property of the replicated
-    model, so all ranks decide alike), and low fp32 variances are recomputed in fp64 inside the owning rank."""
+    mean would leave the stated 1e-4 runs on the fp64 kernels on every rank (`mean_gate`: decided once on the whole batch
+    and combined by an all-reduce, so all ranks decide alike), and low fp32 variances are recomputed in fp64 inside the
+    owning rank (after `replicate()`: by the fitting rank)."""
 
     def __init__(self, gpr, group=None, dtype="float32", gated=True):
         self.gpr, self.group, self.dtype, self.gated = gpr, group, dtype, gated
@@ -205,32 +206,71 @@ class ShardedPredictor:
         comp = g.kernel_.components()
         return comp.sf2 + (comp.noise or 0.0)
 
+    def mean_gate(self, Xq):
+        """The fp32 mean gate for the WHOLE batch, one answer for every rank.  The batch-level check of `fp32_mean_ok` looks at
+        up to 1024 evenly spaced rows of what it is given: given a rank's own shard the ranks can disagree, and a rank that
+        alone switches to the fp64 kernels - a replica cannot even serve fp64 variances - leaves the others waiting in the
+        all-gather.  So every rank evaluates the gate on the full `Xq` (identical everywhere: same rows, same replicated
+        model) and the answers are combined by ONE all-reduce (MIN) for good measure.  None: nothing to decide."""
+        import torch
+        import torch.distributed as dist
+        if not (self.gated and self.dtype == "float32"):
+            return None
+        g = self.gpr
+        g._ensure_device()
+        ok = bool(g._dev.fp32_mean_ok(Xq))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            # (gloo reduces host tensors, RCCL device tensors)
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=g._dev.be.device if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(int(flag.item()))
+        return ok
+
     def predict_mean(self, Xq):
         """Xq: (M, D) tensor or array, identical on every rank -> (M, P) device tensor."""
         g = self.gpr
         g._ensure_device()
+        gate = self.mean_gate(Xq)
         return sharded_predict(
             lambda q: g._dev.predict_gated_dev(q, g._y_train_mean, g._y_train_std, None, 0.0, self.dtype, "auto",
-                                               self.gated)[0], Xq, self.group)
+                                               self.gated, gate)[0], Xq, self.group)
 
     def predict_mean_var(self, Xq):
         import torch
+        import torch.distributed as dist
         g = self.gpr
         g._ensure_device()
         kss = self._kss()
-        out = sharded_predict(
-            lambda q: g._dev.predict_packed_dev(q, g._y_train_mean, g._y_train_std, kss, 0.0, self.dtype, "auto", self.gated),
-            Xq, self.group)
         P = g._dev.P
+        gate = self.mean_gate(Xq)
+        ys = np.broadcast_to(np.asarray(g._y_train_std, dtype=np.float64), (P,))
+
+        def var64(rows):                      # fp64 variances of the caller's rows `rows` (index tensor, or None: all), un-normalised
+            if rows is None:
+                q = Xq if isinstance(Xq, torch.Tensor) else g._dev.be.upload(np.ascontiguousarray(Xq, dtype=np.float64))
+            else:
+                q = Xq[rows] if isinstance(Xq, torch.Tensor) else g._dev.be.upload(np.ascontiguousarray(Xq, dtype=np.float64)[rows.cpu().numpy()])
+            v = g._dev.predict_var_dev(q.to(g._dev.be.device).double().contiguous(), kss, 0.0, "float64", g._dev._fp64_var_method())
+            return v[:, None] * torch.as_tensor(ys ** 2, device=v.device)[None, :]
+
+        if self.src is not None and gate is False:
+            # The batch failed the gate and the model was replicated by broadcast: the replicas hold no factor, so they serve
+            # the fp64 MEANS of their shards (X and alpha are fp64 everywhere) and the fitting rank computes every variance
+            # and hands them out with one broadcast - the same two collectives on every rank, nobody is left waiting.
+            mean = sharded_predict(
+                lambda q: g._dev.predict_gated_dev(q, g._y_train_mean, g._y_train_std, None, 0.0, "float64", "auto", False)[0],
+                Xq, self.group)
+            var = torch.empty((mean.shape[0], P), dtype=torch.float64, device=mean.device)
+            if dist.get_rank(self.group) == self.src:
+                var.copy_(var64(None))
+            dist.broadcast(var, src=self.src, group=self.group)
+            return mean, var
+        out = sharded_predict(
+            lambda q: g._dev.predict_packed_dev(q, g._y_train_mean, g._y_train_std, kss, 0.0, self.dtype, "auto", self.gated, gate),
+            Xq, self.group)
         if self.src is not None and self.gated and self.dtype == "float32":
             # replicas cannot recompute low fp32 variances (no factor): the fitting rank does it for everybody
-            ys = np.broadcast_to(np.asarray(g._y_train_std, dtype=np.float64), (P,))
             thr = g._dev.FP32_VAR_RECHECK_FRACTION * kss * float(ys[0] ** 2)
-
-            def recompute(rows):
-                q = Xq[rows] if isinstance(Xq, torch.Tensor) else g._dev.be.upload(np.ascontiguousarray(Xq, dtype=np.float64)[rows.cpu().numpy()])
-                v = g._dev.predict_var_dev(q.double().contiguous(), kss, 0.0, "float64", g._dev._fp64_var_method())
-                return v[:, None] * torch.as_tensor(ys ** 2, device=v.device)[None, :]
-
-            out, _ = patch_low_rows(out, P, thr, recompute, self.src, self.group)
+            out, _ = patch_low_rows(out, P, thr, var64, self.src, self.group)
         return out[:, :P], out[:, P:]
