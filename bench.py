@@ -286,6 +286,19 @@ def pmc_traffic(kernel_key, N, M):
     return None
 
 
+def pmc_workload_traffic(workload, N):
+    """Fabric/HBM bytes per STEP of a whole workload (tools/pmc_workload.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    very command, set-up cancelled by differencing two step counts), or None when no pass exists for this workload and size."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            for e in json.load(f).get("workloads", []):
+                if e["workload"] == workload and e["n_train"] == N:
+                    return e
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def bench_gram(args, be, rank, world, use_dist, ranks_seen):
     """--workload gram: K1 alone, sharded by row slabs (each rank writes the rows it owns; nothing is exchanged)."""
     import torch
@@ -340,7 +353,9 @@ def bench_gram(args, be, rank, world, use_dist, ranks_seen):
                            "kernel": "gram_strip_kernel (symmetric tiles computed once, written twice)" if world == 1
                                      else "cross_t_kernel per slab (every entry computed directly: no mirroring across ranks)"},
                 "roofline": {"bound": "hbm" if world == 1 else "valu", "achieved": my_bytes / mine / 1e9, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": my_bytes / mine / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                             "unit": "GB/s", "frac": my_bytes / mine / 1e9 / HBM_PEAK_GBPS,
+                             "traffic": (pmc_workload_traffic("gram", N) or {}).get("bytes_per_step") if world == 1 else None,
+                             "traffic_source": (pmc_workload_traffic("gram", N) or {}).get("source") if world == 1 else None,
                              "kernel_ms": mine * 1e3,
                              "note": "rank 0's slab bytes over its own launch time (HIP events); a slab kernel computes every "
                                      "entry (about 45 fp64 operations each), so from two ranks up it is bound by the "
@@ -427,6 +442,7 @@ def bench_train(args, be):
     flops = (len(ge) * 1.0 + (len(gv) + args.steps) * 2.0 / 3.0) * float(N) ** 3 / args.steps
     s_train = dt / args.steps
     s_eval = s_train / max(len(ge) / args.steps, 1)
+    tr = pmc_workload_traffic("train", N)
     line = {
         "metric": "offline GP training wall time: SimpleQuadrotorGP.train_gp() (L-BFGS-B + 1 restart, LML + analytic gradient "
                   "per evaluation) on N_train rows, D=10, P=6",
@@ -442,7 +458,11 @@ def bench_train(args, be):
         "potrf_ms_final_fit": potrf_ms,
         "kernel": str(gm.kernel_), "lml": float(gm.log_marginal_likelihood_value_),
         "roofline": {"bound": "mfma", "achieved": flops / s_train / 1e12, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": flops / s_train / 1e12 / MFMA_F64_PEAK_TF, "traffic": None,
+                     "frac": flops / s_train / 1e12 / MFMA_F64_PEAK_TF,
+                     "traffic": tr["bytes_per_step"] if tr else None,
+                     "traffic_note": ("fabric bytes per train_gp() from the counter passes of this command; by kernel under pmc"
+                                      if tr else "no counter pass for this size"),
+                     "pmc": ({"by_kernel": tr["by_kernel"], "source": tr["source"]} if tr else None),
                      "what": "the fp64 flops of one train_gp() - N^3 per LML + gradient evaluation (factor, inverse factor, "
                              "K^-1 = W^T W; SURVEY 8d K6), 2 N^3 / 3 per value-only evaluation and for the final fit - over its "
                              "wall time, host side of the optimiser, Gram builds and reductions included"},
@@ -532,6 +552,8 @@ def bench_lml(args, be):
     # the HBM peak, which says nothing); the survey's count is kept beside it.
     survey_bytes = 2.0 * N * N * 8
     alg_bytes = Np * (Np + 128) / 2 * 8
+    tr = pmc_workload_traffic("lml", N)
+    gkern = (tr or {}).get("by_kernel", {}).get("lml_grad_kernel")
     line = {
         "metric": "LML + gradient evaluations/s, three per-axis ARD GPs fused into one launch chain (BASELINE configs[4])",
         "value": B / step_s, "unit": "GP evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -539,7 +561,9 @@ def bench_lml(args, be):
         "data": "synthetic (SURVEY 8d generator), ARD l_d = 2.0 (1 + 0.1 d), noise 0.1, jitter 1e-4",
         "config": {"workload": f"C5: N_train={N}, D={D}, B={B} single-output ARD GPs on shared inputs, LML + gradient"},
         "roofline": {"bound": "mfma", "achieved": flops / step_s / 1e12, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": flops / step_s / 1e12 / MFMA_F64_PEAK_TF, "traffic": None,
+                     "frac": flops / step_s / 1e12 / MFMA_F64_PEAK_TF,
+                     "traffic": tr["bytes_per_step"] if tr else None,
+                     "pmc": ({"by_kernel": tr["by_kernel"], "source": tr["source"]} if tr else None),
                      "what": "B x N^3 fp64 flops (factor + inverse factor + W^T W per model) over the step's wall time"},
         "roofline_grad_kernel": {"kernel": "lml_grad_kernel", "bound": "hbm", "achieved": alg_bytes / gk / 1e9,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / gk / 1e9 / HBM_PEAK_GBPS,
@@ -547,7 +571,8 @@ def bench_lml(args, be):
                                  "what": "the lower tiles of K^-1 read once (N^2 / 2 x 8 bytes); K_ij and its D per-feature factors "
                                          "are recomputed per entry on the fp64 vector ALU, which is what the launch is bound by",
                                  "survey_bytes_per_launch": survey_bytes, "ms_per_launch": gk * 1e3,
-                                 "launches_averaged": int(len(grad_ms)), "traffic": None},
+                                 "launches_averaged": int(len(grad_ms)),
+                                 "traffic": (gkern["bytes_per_step"] / max(gkern["launches_per_step"], 1)) if gkern else None},
         "potrf_ms_all_models_one_launch": float(np.mean(potrf_ms)) if len(potrf_ms) else None,
         "lml": [float(v) for v in lml],
         "peak_hbm_bytes_per_rank": int(torch.cuda.max_memory_allocated(be.device)),
@@ -918,7 +943,9 @@ def main():
                 "note": "vector-ALU flops only (exp2 counted as 8 + 2P per pair); the 3D distance flops per pair run "
                         "on the bf16 matrix pipe" if kern == "mfma" else "all flops on the vector ALU",
                 "algorithmic_TFLOPs_all_pipes": flops / k4_s / 1e12,
-                "traffic": None, "k4_ms": k4_s * 1e3, "algorithmic_flops_per_step": flops}
+                "traffic": (pmc_workload_traffic("c4", N) or {}).get("bytes_per_step") if world == 1 else None,
+                "traffic_source": (pmc_workload_traffic("c4", N) or {}).get("source") if world == 1 else None,
+                "k4_ms": k4_s * 1e3, "algorithmic_flops_per_step": flops}
     if rank == 0 and not c4:
         flops = float(N) * float(N) * float(M)      # N^2 M algorithmic (fp32-equivalent) flops per step (K5)
         # per-STEP kernel time: the bracketed launches of one step summed (a batch larger than the variance panel is

@@ -69,8 +69,7 @@ GPK_API int64_t gpk_padded(int64_t n);
  * launches with that tag still in the ring, oldest first (*n_out of them, at most max_n).  bench.py uses it to
  * report the dominant kernel's duration over exactly the timed steps; rocprofv3's kernel trace of the same run is
  * the cross-check.  No reference counterpart (the reference has no instrumentation on this path).        */
-/* gpk_set_option: the tuning knobs a fresh handle reads from the environment (GPK_K5_SPLIT2_TILE, GPK_K5_SUPER,
- * GPK_SMALL_PATH, GPK_TRSM256, GPK_TRTRI_LEVELS, GPK_GEMM_SMALL), settable on a live handle:
+/* gpk_set_option: the handle's tuning knobs (the library reads NOTHING from the environment), settable on a live handle:
  * "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = the tallest of the 512 / 256 / 128 x 128 tiles that still comes in at
  * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256",
  * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
@@ -79,11 +78,19 @@ GPK_API int64_t gpk_padded(int64_t n);
  * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 or 2 such tiles per column), "ptile_single_max_nt" (up to this many tile
  * columns (96) the launch keeps one workgroup per CU instead of two, 0 = always two), "ptile_inv_max_np" (gpk_lml_eval
  * with a gradient: up to this padded size (4608) the tiles of the inverse factor are tasks of the same launch, 0 = always the
- * level-by-level products of gpk_trtri; same values to rounding), "gemm_balanced" (tile GEMMs whose
- * tiles differ in k-range - the products with triangular operands of gpk_trtri / gpk_wtw / gpk_potrs_inv: 1 = the balanced
- * persistent tile schedule, 0 = the static tile mapping; bit-identical results), "gemm_balanced_max_tiles".  Used by the A/B
- * timings and by the tests that pin a fast path to its plain form.                                                   */
+ * level-by-level products of gpk_trtri; same values to rounding), "ptile_xcd" / "ptile_xcd_min_nt" / "ptile_grp_rows" /
+ * "ptile_grp_cols" (XCD-aware dealing of that launch's tasks: 0 = one global ticket counter (default), 1 = one queue per XCD with
+ * the tile rows dealt round-robin, 2 = groups of rows x cols tiles per queue; bit-identical factors, measured slower:
+ * profiles/r05_ptile_xcd_ab.log), "ptile_slots" (resident workgroups of that launch; 0 = by the rule above), "gemm_balanced"
+ * (tile GEMMs whose tiles differ in k-range - the products with triangular operands of gpk_trtri / gpk_wtw / gpk_potrs_inv:
+ * 1 = the balanced persistent tile schedule, 0 = the static tile mapping; bit-identical results), "gemm_balanced_max_tiles",
+ * "gemm_wm_f64" / "gemm_wm_f32" (wave rows per GEMM workgroup, 2 or 4), "gemm_log" (1: every tile-GEMM launch to stderr),
+ * "debug_fill" (1: the handle's scratch and serving work area are overwritten with NaN bytes at every request - the test
+ * suite runs with it).  Used by the A/B timings and by the tests that pin a fast path to its plain form.
+ * gpk_set_option_str: "ptile_trace_path" - the NEXT one-launch factorisation writes its per-task time stamps to that file
+ * (debugging aid, tools/exp_ptile_trace.py).                                                                          */
 GPK_API int gpk_set_option(gpk_handle h, const char* name, int value);
+GPK_API int gpk_set_option_str(gpk_handle h, const char* name, const char* value);
 enum { GPK_TIMED_K5 = 1, GPK_TIMED_GRAM = 2, GPK_TIMED_GRAD = 3, GPK_TIMED_POTRF = 4 };
 GPK_API int gpk_timing(gpk_handle h, int enable);
 GPK_API int gpk_kernel_times(gpk_handle h, int tag, double* ms, int max_n, int* n_out);

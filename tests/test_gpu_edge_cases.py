@@ -210,11 +210,7 @@ def test_fast_paths_match_their_plain_forms(monkeypatch):
     recursion, 64-tile launches vs 128-tile ones, small-batch serving kernels vs the general chain."""
     from unmanned_aerial_vehicles_amd.device import Backend, DeviceGP, get_backend
     fast = get_backend(0)
-    for k, v in (("GPK_TRSM256", "0"), ("GPK_TRTRI_LEVELS", "0"), ("GPK_GEMM_SMALL", "128"), ("GPK_SMALL_PATH", "0")):
-        monkeypatch.setenv(k, v)
-    plain = Backend(0)
-    for k in ("GPK_TRSM256", "GPK_TRTRI_LEVELS", "GPK_GEMM_SMALL", "GPK_SMALL_PATH"):
-        monkeypatch.delenv(k)
+    plain = Backend(0).set_options(trsm256=0, trtri_levels=0, gemm_small_tiles=128, small_path=0)
     rng = np.random.default_rng(5)
     for N in (1000, 2048, 4096, 4961):
         X = rng.standard_normal((N, 8)); Y = np.sin(X @ rng.standard_normal((8, 3))) + 0.1 * rng.standard_normal((N, 3))

@@ -12,6 +12,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from unmanned_aerial_vehicles_amd import GaussianProcessRegressor  # noqa: E402
+from tools import gpk_opts  # noqa: E402
+gpk_opts.install()      # GPK_OPTS=ptile_inv_max_np=0 ...: A/B switches
 from unmanned_aerial_vehicles_amd.kernels import RBF, WhiteKernel  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

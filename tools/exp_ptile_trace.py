@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-task time stamps of the one-launch Cholesky (GPK_PTILE_TRACE): where a step of the critical path goes.
+"""Per-task time stamps of the one-launch Cholesky (option ptile_trace_path): where a step of the critical path goes.
     python tools/exp_ptile_trace.py N"""
 import ctypes as C
 import os
@@ -17,6 +17,8 @@ def main():
     import torch
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import get_backend
+    from tools import gpk_opts
+    gpk_opts.install()
     be = get_backend(0)
     p = lambda t: C.c_void_p(t.data_ptr())
     X = torch.as_tensor(np.random.default_rng(0).standard_normal((n, 9)), device=be.device)
@@ -30,9 +32,8 @@ def main():
         K = K0.clone()
         torch.cuda.synchronize()
         if it == 2:
-            os.environ["GPK_PTILE_TRACE"] = path
+            be.set_options(ptile_trace_path=path)
         be.check(be.lib.gpk_potrf(be.h, p(K), n, ld, p(winv), C.byref(info)))
-    os.environ.pop("GPK_PTILE_TRACE", None)
     t = np.loadtxt(path)
     sub = t[-4:].ravel()
     if sub[0] > 0:      # a library built with -DGPK_PTILE_SUBSTAMPS=<step>: one 16-column step of D(2) in shader cycles
@@ -55,7 +56,8 @@ def main():
                 ph = " ".join(f"{us(r[2 + b]):7.1f}" for b in range(8))
                 clk = (r[15] - r[14]) / max(r[10] - r[0], 1) * 100.0
                 print(f"      shader clock over the task: {clk:.0f} MHz")
-                print(f"D({j:2d})     start {us(r[0]):7.1f} lastcol-seen {us(r[11]):7.1f} kt-8 {us(r[12]):7.1f} kt-4 {us(r[13]):7.1f} kloop {us(r[1]):7.1f} | phaseA ends {ph} | done {us(r[10]):7.1f}")
+                # (merged task: stamps 12 / 13 are the forward substitution's first poll passed / its end)
+                print(f"D({j:2d})     start {us(r[0]):7.1f} lastcol-seen {us(r[11]):7.1f} kt-8|sub-start {us(r[12]):7.1f} kt-4|sub-end {us(r[13]):7.1f} kloop {us(r[1]):7.1f} | phaseA ends {ph} | done {us(r[10]):7.1f}")
             elif i <= j + 2 or i == nt - 1:
                 print(f"T({i:2d},{j:2d})  start {us(r[0]):7.1f} kloop {us(r[1]):7.1f} Wready {us(r[2]):7.1f} Wlds {us(r[3]):7.1f} "
                       f"apply {us(r[4]):7.1f} done {us(r[5]):7.1f}")

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """GaussianProcessRegressor.fit with the optimiser and one restart at a small size (P = 6 outputs), restarts side by side or one
-after the other.    python tools/exp_train_small.py N [concurrent: 1 | 0]   (GPK_PTILE_INV_NP=0: level-by-level inverse factor)"""
+after the other.    python tools/exp_train_small.py N [concurrent: 1 | 0]   (GPK_OPTS=ptile_inv_max_np=0: level-by-level inverse factor)"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import synthetic_problem
 from unmanned_aerial_vehicles_amd import GaussianProcessRegressor
+from tools import gpk_opts  # noqa: E402
+gpk_opts.install()      # GPK_OPTS=ptile_inv_max_np=0 ...: A/B switches
 from unmanned_aerial_vehicles_amd.kernels import RBF, WhiteKernel
 N = int(sys.argv[1]); conc = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 X, Y, _ = synthetic_problem(N, 1, D=10, P=6)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Join the GPK_GEMM_LOG lines (stderr, launch order) of tools/exp_potrf_trace.py with the rocprofv3 kernel
+"""Join the gemm_log lines (GPK_OPTS=gemm_log=1) (stderr, launch order) of tools/exp_potrf_trace.py with the rocprofv3 kernel
 trace: time and TFLOP/s per class of GEMM launch.  usage: join_gemm_trace.py <stderr log> <kernel_trace.csv>"""
 import collections
 import csv

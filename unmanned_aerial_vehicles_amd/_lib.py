@@ -46,6 +46,7 @@ SIGNATURES = {
                                            _dbl, _dbl, _vp, _vp, _dbl, _vp, _vp]),
     "gpk_pack_mean_var": (_int, [_vp, _int, _vp, _vp, _i64, _int, _dp, _vp]),
     "gpk_set_option": (_int, [_vp, C.c_char_p, _int]),
+    "gpk_set_option_str": (_int, [_vp, C.c_char_p, C.c_char_p]),
     "gpk_timing": (_int, [_vp, _int]),
     "gpk_kernel_times": (_int, [_vp, _int, _dp, _int, C.POINTER(_int)]),
     "gpk_batch_begin": (_int, [_vp, _int]),

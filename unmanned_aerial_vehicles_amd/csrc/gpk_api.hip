@@ -25,24 +25,7 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
     return GPK_HIP_ERROR;
   }
   h->stream = h->own_stream;
-  if (const char* e = getenv("GPK_GEMM_WM_F64")) h->gemm_wm_f64 = (e[0] == '2') ? 2 : 4;
-  if (const char* e = getenv("GPK_GEMM_WM_F32")) h->gemm_wm_f32 = (e[0] == '2') ? 2 : 4;
-  if (const char* e = getenv("GPK_GEMM_SMALL")) h->gemm_small_tiles = atoi(e);
-  if (const char* e = getenv("GPK_GEMM_BALANCED")) h->gemm_balanced = atoi(e);
-  if (const char* e = getenv("GPK_GEMM_BALANCED_MAX")) h->gemm_balanced_max_tiles = atoll(e);
-  if (const char* e = getenv("GPK_K5_SUPER")) h->k5_super = atoi(e);
-  if (const char* e = getenv("GPK_K5_SPLIT2_TILE")) { const int v = atoi(e); h->k5_split2_tile = (v >= 0 && v <= 2) ? v : 0; }
-  if (const char* e = getenv("GPK_SMALL_PATH")) h->small_path = atoi(e);
-  if (const char* e = getenv("GPK_TRSM256")) h->trsm256 = atoi(e);
-  if (const char* e = getenv("GPK_TRTRI_LEVELS")) h->trtri_levels = atoi(e);
-  if (const char* e = getenv("GPK_GEMM_LOG")) h->gemm_log = atoi(e);
-  if (const char* e = getenv("GPK_PTILE")) h->ptile = atoi(e);
-  if (const char* e = getenv("GPK_PTILE_MAX_NP")) h->ptile_max_np = atoi(e);
-  if (const char* e = getenv("GPK_PTILE_PROG_NT")) h->ptile_prog_max_nt = atoi(e);
-  if (const char* e = getenv("GPK_PTILE_INV_NP")) h->ptile_inv_max_np = atoi(e);
-  if (const char* e = getenv("GPK_PTILE_SINGLE_NT")) h->ptile_single_max_nt = atoi(e);
-  if (const char* e = getenv("GPK_PTILE_PROG_ROWS")) h->ptile_prog_rows = atoi(e) >= 2 ? 2 : 1;
-  if (getenv("GPK_DEBUG_FILL")) h->debug_fill = 1;
+  // (the handle reads nothing from the environment: every knob is a gpk_set_option / gpk_set_option_str name)
   *out = h;
   return GPK_OK;
 }
@@ -98,6 +81,11 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "gemm_balanced") h->gemm_balanced = value;
   else if (n == "gemm_balanced_max_tiles") h->gemm_balanced_max_tiles = value;
   else if (n == "k3_stream_min_np") h->k3_stream_min_np = value;
+  else if (n == "gemm_wm_f64") h->gemm_wm_f64 = value == 2 ? 2 : 4;
+  else if (n == "gemm_wm_f32") h->gemm_wm_f32 = value == 2 ? 2 : 4;
+  else if (n == "gemm_log") h->gemm_log = value;
+  else if (n == "debug_fill") h->debug_fill = value ? 1 : 0;
+  else if (n == "ptile_slots") h->ptile_slots_override = value > 0 ? value : 0;
   else if (n == "ptile") h->ptile = value;
   else if (n == "ptile_max_np") h->ptile_max_np = value;
   else if (n == "ptile_prog_max_nt") h->ptile_prog_max_nt = value;
@@ -108,6 +96,15 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "ptile_grp_cols") h->ptile_grp_cols = value;
   else if (n == "ptile_xcd_min_nt") h->ptile_xcd_min_nt = value;
   else if (n == "ptile_prog_rows") h->ptile_prog_rows = value >= 2 ? 2 : 1;
+  else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
+  return GPK_OK;
+}
+
+extern "C" int gpk_set_option_str(gpk_handle h, const char* name, const char* value) {
+  if (!h) return GPK_BAD_ARG;
+  GPK_REQUIRE(h, name, "set_option_str: null name");
+  const std::string n(name);
+  if (n == "ptile_trace_path") h->ptile_trace_request = value ? value : "";
   else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
   return GPK_OK;
 }

@@ -675,7 +675,7 @@ int gpk_gemm_tile(gpk_handle h, const GemmArgs& g) {
 
 int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   const int bk = dtype == GPK_F64 ? 16 : 32;
-  if (h->gemm_log)   // GPK_GEMM_LOG=1: one line per launch, in launch order (joined with a rocprofv3 kernel trace)
+  if (h->gemm_log)   // option gemm_log = 1: one line per launch, in launch order (joined with a rocprofv3 kernel trace)
     fprintf(stderr, "GPKGEMM %d %d %d %d ta%d tb%d lo%d kb %d %d %d ke %d %d %d\n", dtype, g.m, g.n, g.k, g.ta, g.tb,
             g.lower_only, g.kb0, g.kb_row, g.kb_col, g.ke0, g.ke_row, g.ke_col);
   GPK_REQUIRE(h, g.m > 0 && g.n > 0 && g.m % 128 == 0 && g.n % 128 == 0, "gemm: m, n must be multiples of 128");
@@ -693,7 +693,7 @@ int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   // the 128-wide leaves of the triangular solves) rely on one tile covering everything it reads and keep 128.
   const bool small = gpk_gemm_tile(h, g) == 64;
   // wave rows per 128-tile workgroup (2 -> 256 threads, 4 -> 512 threads), per dtype; tuned on MI355X,
-  // overridable through GPK_GEMM_WM_F64 / GPK_GEMM_WM_F32 (read once per handle)
+  // overridable through the options gemm_wm_f64 / gemm_wm_f32
   if (dtype == GPK_F64) {
     if (small) return launch<double, 2, 64>(h, g);
     return h->gemm_wm_f64 == 2 ? launch<double, 2, 128>(h, g) : launch<double, 4, 128>(h, g);

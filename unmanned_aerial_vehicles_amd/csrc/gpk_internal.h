@@ -35,27 +35,27 @@ struct gpk_context {
   size_t serve_host_bytes = 0;
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
-  int gemm_small_tiles = 1024;   // launches with fewer 128 x 128 tiles than this run on 64 x 64 tiles (GPK_GEMM_SMALL)
-  int gemm_balanced = 1;         // launches whose tiles differ in k-range: balanced persistent tile schedule (GPK_GEMM_BALANCED=0: static)
+  int gemm_small_tiles = 1024;   // launches with fewer 128 x 128 tiles than this run on 64 x 64 tiles
+  int gemm_balanced = 1;         // launches whose tiles differ in k-range: balanced persistent tile schedule
   long long gemm_balanced_max_tiles = 32768;   // ... up to this many tiles per launch (all problems of a batch)
   int cus = 0;                   // compute units of the device (read once)
-  int trtri_levels = 1;      // gpk_trtri: one batched launch per level for power-of-two tile counts (GPK_TRTRI_LEVELS=0: recursion)
-  int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve (GPK_TRSM256=0: three launches)
-  int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (GPK_SMALL_PATH=0 disables)
-  int k5_super = 1;          // K5: lockstep super-tiles (GPK_K5_SUPER=0 disables)
+  int trtri_levels = 1;      // gpk_trtri: one batched launch per level for power-of-two tile counts
+  int trsm256 = 1;           // potrf: fused 256-wide base of the triangular solve
+  int small_path = 1;        // gpk_predict_host: two-launch small-batch kernels (option small_path = 0 disables)
+  int k5_super = 1;          // K5: lockstep super-tiles (option k5_super = 0 disables)
   int k3_stream_min_np = 512;    // gpk_potrs_inv: streaming matrix-vector passes from this padded size up (P <= 6); measured faster than the two
                                  // 128-column tile GEMMs from there on (N = 4096: 0.11 against 0.35 ms, profiles/r04_k3_ab.log)
   int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
-                             // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0 (GPK_K5_SPLIT2_TILE)
-  int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 512 <= Np <= ptile_max_np (GPK_PTILE=0: recursion)
+                             // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0
+  int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 512 <= Np <= ptile_max_np
   int ptile_max_np = 16384;
   int ptile_prog_max_nt = 128;  // ... up to this many tile columns the two tiles under a diagonal tile follow that tile's factorisation 16
-                             // columns at a time instead of waiting for the whole inverse (GPK_PTILE_PROG_NT; 0: never)
-  int ptile_inv_max_np = 4608;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (GPK_PTILE_INV_NP; 0: never)
-  int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so (GPK_PTILE_PROG_ROWS)
+                             // columns at a time instead of waiting for the whole inverse (0: never)
+  int ptile_inv_max_np = 4608;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (0: never)
+  int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
-  int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU (GPK_PTILE_SINGLE_NT)
+  int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU
   int ptile_xcd = 0;         // 1: one task queue per XCD, tile rows dealt round-robin; 2: groups of rows x columns tiles per queue; 0: ONE
                              // global ticket counter - the default: measured, neither dealing raises the L2 hit rate (the tasks of an XCD
                              // do not walk k in step) and both are 0-4 % slower (profiles/r05_ptile_xcd_ab.log)
@@ -66,10 +66,12 @@ struct gpk_context {
   std::vector<int> ptile_list_host;
   long long ptile_list_key = -1;
   int ptile_launches = 0;    // one-launch factorisations issued by the current gpk_potrf (their abort words are checked at its end)
-  std::string ptile_trace_path;   // GPK_PTILE_TRACE (debugging aid): where the next launch's time stamps go
+  std::string ptile_trace_request;   // option "ptile_trace_path" (debugging aid): the NEXT one-launch factorisation writes its per-task time stamps there
+  int ptile_slots_override = 0;      // option "ptile_slots" (experiments): resident workgroups of the launch, 0 = the rule below
+  std::string ptile_trace_path;   // ... while that launch is in flight
   long long ptile_trace_n = 0;
-  int debug_fill = 0;        // GPK_DEBUG_FILL set: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
-  int gemm_log = 0;          // GPK_GEMM_LOG=1: log every tile-GEMM launch to stderr (profiling aid)
+  int debug_fill = 0;        // option debug_fill: the handle's scratch is overwritten with 0xFF bytes (NaN) at every request
+  int gemm_log = 0;          // option gemm_log = 1: log every tile-GEMM launch to stderr (profiling aid)
   // gpk_timing: HIP-event brackets around the dominant launches (K5 variance GEMM, K1 Gram kernel), a ring of pairs
   struct TimedLaunch { hipEvent_t e0 = nullptr, e1 = nullptr; int tag = 0; };
   int timing = 0;

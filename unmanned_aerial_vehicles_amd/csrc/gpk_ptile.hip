@@ -99,7 +99,7 @@ struct PTParams {
   int* ctrl;                                       // [0] ticket counter, [1] abort; ready counters from ctrl + 16;
                                                    // "a critical diagonal task runs on this CU" words from ctrl + PAUSE_OFF;
                                                    // progress of the diagonal tiles' factorisations from ctrl + PROG_OFF
-  long long* trace;                                // GPK_PTILE_TRACE: 16 time stamps per task (100 MHz), or null
+  long long* trace;                                // option ptile_trace_path: 16 time stamps per task (100 MHz), or null
   // XCD-aware dealing (null: ONE global ticket, tasks computed from the ticket): the task list cut into PT_QUEUES queues, each in
   // the global (column-major) order; entry = i | j << 9 | problem << 18.  list[0 .. 8] = the queues' offsets, queue q =
   // list[16 + off[q] .. 16 + off[q + 1]); its head is the ticket counter ctrl[QHEAD_OFF + q]; the workgroups of XCD q take from
@@ -1082,7 +1082,9 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
     }
     p.list = h->d_ptile_list;
   }
-  if (const char* tp = getenv("GPK_PTILE_TRACE")) {        // debugging aid: per-task time stamps to the file named there
+  if (!h->ptile_trace_request.empty()) {                   // debugging aid (option "ptile_trace_path"): per-task time stamps to that file
+    const std::string tp = h->ptile_trace_request;
+    h->ptile_trace_request.clear();
     void* ws = nullptr;
     GPK_TRY(gpk_scratch(h, ((size_t)ntasks * 16 + 64) * sizeof(long long), &ws));
     GPK_CHECK_HIP(h, hipMemsetAsync(ws, 0, ((size_t)ntasks * 16 + 64) * sizeof(long long), h->stream));
@@ -1096,7 +1098,7 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   // workgroups: N = 4096 1.21 / 1.37 ms, 5120 1.57 / 1.85, 8192 3.92 / 4.45, 10 112 6.65 / 7.10; 16 384 25.8 / 25.5: from
   // there on the launch is throughput and two per CU win; 320 or 384 - some CUs with two - lose to both).
   int slots = nt <= h->ptile_single_max_nt ? h->ptile_slots / 2 : h->ptile_slots;
-  if (const char* e = getenv("GPK_PTILE_SLOTS")) slots = atoi(e) > 0 ? atoi(e) : slots;      // (experiments)
+  if (h->ptile_slots_override > 0) slots = h->ptile_slots_override;      // (experiments: option "ptile_slots")
   const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
   hipLaunchKernelGGL(ptile_potrf_kernel, dim3(grid), dim3(NT), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);

@@ -47,6 +47,8 @@ class Backend:
             raise GPKError(rc, "gpk_create failed")
         self.h = h
         self.lock = threading.RLock()
+        if os.environ.get("GPK_DEBUG_FILL"):      # debugging aid (the test suite sets it): poison the handle's scratch too
+            self.check(self.lib.gpk_set_option(self.h, b"debug_fill", 1))
         self.bind_stream()
         # running count of the rows the fp32 variance gate sent back (the packed finalise kernel adds to it and nobody
         # resets it: a serving call reads it before and after under the lock, so no fill kernel runs per call)
@@ -68,6 +70,16 @@ class Backend:
 
     def sync(self):
         self.check(self.lib.gpk_synchronize(self.h))
+
+    def set_options(self, **opts):
+        """Tuning knobs of the handle (include/gpk.h, gpk_set_option): `be.set_options(ptile=0, trtri_levels=0)`; a str value
+        goes to gpk_set_option_str.  The library itself reads nothing from the environment."""
+        for k, v in opts.items():
+            if isinstance(v, str):
+                self.check(self.lib.gpk_set_option_str(self.h, k.encode(), v.encode()))
+            else:
+                self.check(self.lib.gpk_set_option(self.h, k.encode(), int(v)))
+        return self
 
     def empty(self, shape, dtype):
         t = _torch().empty(shape, dtype=dtype, device=self.device)
