@@ -17,10 +17,11 @@ extern "C" int gpk_create(gpk_handle* out, int device) {
   h->device = device;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&h->d_info, GPK_MAX_BATCH * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->d_small, 4096) != hipSuccess ||
+
       hipMalloc((void**)&h->d_count, 2 * GPK_SMALL_MAX_MODELS * sizeof(unsigned)) != hipSuccess ||
       hipMemset(h->d_count, 0, 2 * GPK_SMALL_MAX_MODELS * sizeof(unsigned)) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_small, 4096, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&h->h_small, 4096, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->d_small, h->h_small, 0) != hipSuccess) {
     delete h;
     return GPK_HIP_ERROR;
   }
@@ -37,7 +38,6 @@ extern "C" void gpk_destroy(gpk_handle h) {
   gpk_model_free(h);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->d_info) (void)hipFree(h->d_info);
-  if (h->d_small) (void)hipFree(h->d_small);
   if (h->d_count) (void)hipFree(h->d_count);
   if (h->d_ptile) (void)hipFree(h->d_ptile);
   if (h->d_ptile_list) (void)hipFree(h->d_ptile_list);

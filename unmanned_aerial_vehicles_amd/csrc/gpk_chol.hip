@@ -306,10 +306,17 @@ __global__ void copy_leaf_kernel(const double* __restrict__ w0, double* __restri
 __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict__ L, long long N, long long ldl,
                                                         const double* __restrict__ Y,
                                                         const double* __restrict__ alpha, int P,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, const int* __restrict__ d_info,
+                                                        const int* __restrict__ gave_up, int nb, int* __restrict__ status) {
   // blockIdx.x == 0: log-det term; blockIdx.x == 1 + p: quadratic term of output p
   __shared__ double red[4];
   const int tid = threadIdx.x, b = blockIdx.x;
+  // (status != null: the evaluation chain's status words ride along - the pivot failures of the nb problems and the one-launch
+  // factorisation's "gave up" flag next to the results, what was a launch of its own: gpk_status_enqueue)
+  if (status && b == 0) {
+    if (tid < nb) status[tid] = d_info[tid];
+    if (tid == GPK_MAX_BATCH) status[tid] = gave_up ? *gave_up : 0;
+  }
   double s = 0.0;
   if (b == 0) {
     for (long long i = tid; i < N; i += 256) s += log(L[i * ldl + i]);
@@ -929,11 +936,13 @@ extern "C" int gpk_trsm_lower_left(gpk_handle h, int dtype, const void* L, int64
 
 // the launch of gpk_lml_terms: 1 + P doubles to dout (device)
 int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
-                          double* dout) {
+                          double* dout, int with_status) {
   GPK_REQUIRE(h, L && Y && alpha, "lml_terms: null pointer");
   GPK_REQUIRE(h, P >= 1 && P <= GPK_MAX_P && N >= 1, "lml_terms: bad sizes");
   hipLaunchKernelGGL(lml_terms_kernel, dim3(1 + P), dim3(256), 0, h->stream, L, (long long)N, (long long)ldl, Y,
-                     alpha, P, dout);
+                     alpha, P, dout, (const int*)h->d_info,
+                     h->ptile_launches > 0 ? (const int*)(h->d_ptile + GPK_PTILE_CTRL_INTS) : (const int*)nullptr, h->batch,
+                     with_status ? reinterpret_cast<int*>(h->d_small + GPK_STATUS_OFF) : (int*)nullptr);
   GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }
@@ -942,8 +951,7 @@ extern "C" int gpk_lml_terms(gpk_handle h, const double* L, int64_t N, int64_t l
                              const double* alpha, int P, double* terms) {
   if (!h) return GPK_BAD_ARG;
   GPK_REQUIRE(h, terms, "lml_terms: null pointer");
-  GPK_TRY(gpk_lml_terms_enqueue(h, L, N, ldl, Y, alpha, P, h->d_small));
-  GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, (1 + P) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GPK_TRY(gpk_lml_terms_enqueue(h, L, N, ldl, Y, alpha, P, h->d_small));     // (d_small is the pinned block itself: no copy)
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < 1 + P; ++i) terms[i] = h->h_small[i];
   return GPK_OK;

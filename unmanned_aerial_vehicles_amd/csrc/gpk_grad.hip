@@ -199,10 +199,8 @@ extern "C" int gpk_lml_grad(gpk_handle h, const double* X, int64_t N, int D, con
   GPK_REQUIRE(h, grad, "lml_grad: null pointer");
   double* dout = h->d_small + 64;
   GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls, sf2, alpha, P, Kinv, ldk, dout));
-  double host[GW];
-  GPK_CHECK_HIP(h, hipMemcpyAsync(host, dout, sizeof host, hipMemcpyDeviceToHost, h->stream));
-  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
-  grad_from_sums(host, D, noise, grad);
+  GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));            // (d_small is the pinned block h_small itself)
+  grad_from_sums(h->h_small + 64, D, noise, grad);
   return GPK_OK;
 }
 
@@ -229,13 +227,13 @@ int gpk_lml_chain_batched(gpk_handle h, int B, const double* X, int64_t N, int D
     if (Kinv) GPK_TRY(gpk_wtw(h, W, Np, Np, Kinv, Np));
     // per problem: terms to d_small[4 b ..], gradient sums to d_small[64 + 32 b ..]; then everything back in one copy
     for (int b = 0; b < B; ++b) {
-      GPK_TRY(gpk_lml_terms_enqueue(h, K + b * nn, N, Np, Yn + (size_t)b * Ne, alpha + (size_t)b * Ne, 1, h->d_small + 4 * b));
+      GPK_TRY(gpk_lml_terms_enqueue(h, K + b * nn, N, Np, Yn + (size_t)b * Ne, alpha + (size_t)b * Ne, 1, h->d_small + 4 * b,
+                                    b == B - 1));          // (the last one also writes the chain's status words)
       if (Kinv)
         GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls + (size_t)b * D, sf2[b], alpha + (size_t)b * Ne, 1, Kinv + b * nn, Np,
                                      h->d_small + 64 + 32 * b));
     }
-    GPK_TRY(gpk_status_enqueue(h));
-    GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, 4096, hipMemcpyDeviceToHost, h->stream));
+    // (terms, gradient sums and status words are written straight into the pinned block: one synchronisation, no copy)
     GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
     const int* hst = reinterpret_cast<const int*>(h->h_small + GPK_STATUS_OFF);
     const int rc = gpk_potrf_finish(h, hst, info, hst[GPK_MAX_BATCH]);
@@ -264,9 +262,10 @@ extern "C" int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, con
   GPK_REQUIRE(h, Np == gpk_padded(N) && P >= 1 && P <= GPK_MAX_P, "lml_eval: bad sizes");
   GPK_REQUIRE(h, grad == nullptr || Kinv != nullptr, "lml_eval: the gradient needs the Kinv buffer");
   GPK_TRY(gpk_gram(h, GPK_F64, X, N, D, ls, sf2, diag_add, K, Np));
-  // small matrices, gradient wanted (Kinv is free until W^T W writes it): factor and inverse factor as ONE persistent launch
+  // small matrices (Kinv given: it is free until W^T W writes it - a value-only evaluation may pass it as scratch just for this):
+  // factor and inverse factor as ONE persistent launch
   int fused = 0;
-  if (grad) GPK_TRY(gpk_potrf_trtri_enqueue(h, K, Np, Np, winv, W, Np, Kinv, &fused));
+  if (Kinv) GPK_TRY(gpk_potrf_trtri_enqueue(h, K, Np, Np, winv, W, Np, Kinv, &fused));
   if (!fused) {
     GPK_TRY(gpk_potrf_enqueue(h, K, Np, Np, winv));
     GPK_TRY(gpk_trtri(h, K, Np, Np, winv, W, Np, work));
@@ -274,14 +273,13 @@ extern "C" int gpk_lml_eval(gpk_handle h, const double* X, int64_t N, int D, con
   GPK_TRY(gpk_potrs_inv(h, W, Np, Np, Yn, N, P, alpha));
   double* dterms = h->d_small;            // [0, 1 + P): the terms; [64, 64 + GW): the gradient sums; then the pivot failure
   double* dgrad = h->d_small + 64;
-  GPK_TRY(gpk_lml_terms_enqueue(h, K, N, Np, Yn, alpha, P, dterms));
+  GPK_TRY(gpk_lml_terms_enqueue(h, K, N, Np, Yn, alpha, P, dterms, 1));    // (+ the status words: pivot failure, "gave up")
   if (grad) {
     GPK_TRY(gpk_wtw(h, W, Np, Np, Kinv, Np));
     GPK_TRY(gpk_lml_grad_enqueue(h, X, N, D, ls, sf2, alpha, P, Kinv, Np, dgrad));
   }
-  // ONE copy to pinned memory: terms, gradient sums, the pivot failure and the one-launch factorisation's flag
-  GPK_TRY(gpk_status_enqueue(h));
-  GPK_CHECK_HIP(h, hipMemcpyAsync(h->h_small, h->d_small, 4096, hipMemcpyDeviceToHost, h->stream));
+  // terms, gradient sums, the pivot failure and the one-launch factorisation's flag were written straight into the pinned,
+  // device-mapped block: ONE synchronisation, no copy command, no status launch
   GPK_CHECK_HIP(h, hipStreamSynchronize(h->stream));
   const int* hst = reinterpret_cast<const int*>(h->h_small + GPK_STATUS_OFF);
   GPK_TRY(gpk_potrf_finish(h, hst, info, hst[GPK_MAX_BATCH]));   // GPK_NOT_PD: what follows the factorisation ran on a finite, meaningless factor

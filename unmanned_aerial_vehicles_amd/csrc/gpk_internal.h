@@ -25,8 +25,8 @@ struct gpk_context {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   int* d_info = nullptr;        // device int for potrf pivot failures
-  double* d_small = nullptr;    // 4 KiB device doubles for reductions
-  double* h_small = nullptr;    // pinned host mirror
+  double* h_small = nullptr;    // 4 KiB of pinned, device-mapped host memory: the reductions' results (LML terms, gradient sums, status words)
+  double* d_small = nullptr;    // ... its device address: the kernels write there, the host reads h_small after the synchronisation - no copy command
   unsigned* d_count = nullptr;  // 2 x 8 zero-initialised ticket counters (last-workgroup reductions, gpk_small.hip)
   // staging of gpk_predict_host: device block [Xq | mean | var | K* work] and its pinned host mirror [Xq | mean | var]
   void* serve_dev = nullptr;
@@ -142,7 +142,7 @@ int gpk_tril_block_absmax_f64_enqueue(gpk_handle h, const double* W, int64_t n, 
 int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, double* W, int64_t ldw, double* wt,
                             int* used);   // factor + inverse factor as one persistent launch (small matrices), or *used = 0
 int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
-                          double* dout);
+                          double* dout, int with_status = 0);   // with_status: + what gpk_status_enqueue writes, in the same launch
 int gpk_lml_grad_enqueue(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, const double* alpha,
                          int P, const double* Kinv, int64_t ldk, double* dout);
 // B single-output evaluations on shared X as ONE chain with ONE synchronisation (gpk_lml_batched): the buffers hold the B

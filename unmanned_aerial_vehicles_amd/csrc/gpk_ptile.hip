@@ -79,6 +79,9 @@ constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
 constexpr int YPROG_OFF = XPROG_OFF + 8 * 512; // ctrl ints: per tile row i, likewise for tile (i, i - 2)
 constexpr int WT_OFF = YPROG_OFF + 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
+#ifndef PT_LATE1
+#define PT_LATE1 4                            // diagonal task: block rows are published two steps late up to this step, one step late from it on
+#endif
 constexpr int XS = 18;                        // row stride (doubles) of a wave's 16 x 16 output staging block
 static_assert((22 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: two L images, the waves' W blocks and staging blocks");
 
@@ -919,20 +922,35 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         // more.)  The last step publishes a phase early instead (above), and the end of the task everything.
         // (p.prog = 0: a launch without the 16-column hand-overs - the A/B switch ptile_prog_max_nt.)
         // (with W^T in the launch the waves of the inverse columns issue four more stores per step: 8, the factoring wave 12)
+        // From step PT_LATE1 on the lag is ONE step: by then the previous column's tiles are out and an acknowledgement takes
+        // ~2.5 us, less than a step - and the tile under this one, which cannot start a block row before it is published, is one
+        // step closer behind when this task ends.
+        constexpr bool ONE = JB >= PT_LATE1;
         if (p.prog) {
           if (Wt) {
-            if (rw > JB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (rw == JB - 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (ONE) {
+              if (rw > JB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+              else if (rw == JB) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+              if (rw > JB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              else if (rw == JB - 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
           } else {
-            if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (ONE) {
+              if (rw == JB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+              if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
           }
         }
         if (rw == JB + 1) PT_SUB(11);
         __syncthreads();
         if (rw == JB + 1) PT_SUB(12);
-        if (p.prog && JB >= 2 && tid == 0) st_agent(wprog, JB - 1);
+        if (p.prog && JB >= 2 && tid == 0) st_agent(wprog, ONE ? JB : JB - 1);
       });
       wait_vm0();
       __syncthreads();

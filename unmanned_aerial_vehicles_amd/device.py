@@ -144,6 +144,8 @@ class DeviceGP:
     # up to this padded size the inverse factor W = L^-1 is formed right away (cheap), so that alpha and
     # every later variance / gradient call are single launches
     INVERSE_EAGER_NP = 32768
+    # up to this padded size factor + inverse factor are one launch given an (Np, Np) scratch (the library's ptile_inv_max_np)
+    FUSED_INVERSE_NP = 4608
     MAX_FEATURES = 16
 
     def __init__(self, X, Yn, backend: Backend | None = None):
@@ -303,7 +305,10 @@ class DeviceGP:
         self.factored = False
         W = be.empty((self.Np, self.Np), torch.float64)
         work = be.empty(((self.Np // 2 + 128) ** 2,), torch.float64)
-        if eval_gradient and self._Kinv is None:
+        # (K^-1 buffer: the gradient's, and - up to FUSED_INVERSE_NP rows - the scratch that lets factor and inverse factor run as
+        # ONE persistent launch also in a value-only evaluation: the final fit at the selected hyper-parameters)
+        want_kinv = eval_gradient or self.Np <= self.FUSED_INVERSE_NP
+        if want_kinv and self._Kinv is None:
             self._Kinv = be.empty((self.Np, self.Np), torch.float64)
         terms = np.zeros(1 + self.P)
         g = np.zeros(self.D + 2) if eval_gradient else None
@@ -314,7 +319,7 @@ class DeviceGP:
             be.check(be.lib.gpk_lml_eval(
                 be.h, _p(self.X), self.N, self.D, ls.ctypes.data_as(_lib._dp), float(sf2), float(diag_add), float(noise),
                 _p(self.Yn), self.P, _p(self.K), self.Np, _p(self.winv), _p(W), _p(work), _p(self.alpha),
-                _p(self._Kinv) if eval_gradient else None, terms.ctypes.data_as(_lib._dp),
+                _p(self._Kinv) if want_kinv else None, terms.ctypes.data_as(_lib._dp),
                 g.ctypes.data_as(_lib._dp) if eval_gradient else None, C.byref(info)))
         self.factored = True
         self._Winv["f64"] = W

@@ -120,18 +120,16 @@ class GaussianProcessRegressor:
             lml_from_final_factor = True
 
         # final factorisation at the selected theta (_gpr.py:343-364); not-PD raises here
-        comp = self.kernel_.components()
+        dev = self._dev
         try:
-            self._dev.factorize(comp.ls_vector(X.shape[1]), comp.sf2, (comp.noise or 0.0) + float(self.alpha))
+            logdet_half, quad = self._refactor()
         except NotPositiveDefinite as exc:
             exc.args = (f"The kernel, {self.kernel_}, is not returning a positive definite matrix. Try gradually "
                         "increasing the 'alpha' parameter of your GaussianProcessRegressor estimator.",) + exc.args
             raise
-        self._dev.solve_alpha()
         if lml_from_final_factor:
-            logdet_half, quad = self._dev.lml_terms()
             self.log_marginal_likelihood_value_ = float(
-                np.sum(-0.5 * quad - logdet_half - 0.5 * self._dev.N * LOG_2PI))
+                np.sum(-0.5 * quad - logdet_half - 0.5 * dev.N * LOG_2PI))
         self._alpha_host = None
         self._L_host = None
         return self
@@ -311,9 +309,20 @@ class GaussianProcessRegressor:
         return self._L_host
 
     def _refactor(self):
+        """The model's factorisation at `kernel_` (final step of fit, and again after unpickling: same route, same bits):
+        Gram, factor, inverse factor, alpha and the LML terms as ONE launch chain with one synchronisation (gpk_lml_eval, value
+        only; up to 4608 rows factor and inverse factor are one launch) - or, beyond 32 768 rows and 16 features, call by call.
+        Returns (log-det / 2, [y_p . alpha_p]).  Raises NotPositiveDefinite."""
         comp = self.kernel_.components()
-        self._dev.factorize(comp.ls_vector(self.n_features_in_), comp.sf2, (comp.noise or 0.0) + float(self.alpha))
-        self._dev.solve_alpha()
+        dev, D = self._dev, self.n_features_in_
+        diag = (comp.noise or 0.0) + float(self.alpha)
+        if dev.Np <= dev.INVERSE_EAGER_NP and D <= 16:
+            logdet_half, quad, _ = dev.lml_eval(comp.ls_vector(D), comp.sf2, diag, comp.noise or 0.0, False)
+            dev.release_grad_buffers()
+            return logdet_half, quad
+        dev.factorize(comp.ls_vector(D), comp.sf2, diag)
+        dev.solve_alpha()
+        return dev.lml_terms()
 
     def _ensure_device(self):
         """Re-create the HBM state after unpickling (deterministic refactorisation)."""
