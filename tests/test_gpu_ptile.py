@@ -181,3 +181,27 @@ def test_one_launch_handovers_on_and_off(be, n):
     finally:
         be.check(be.lib.gpk_set_option(be.h, b"ptile_single_max_nt", 96))
     assert info3 == 0 and np.array_equal(np.tril(L3), L1) and np.array_equal(W3, W1)
+
+
+@pytest.mark.parametrize("n", [640, 2048, 3000])
+def test_xcd_aware_dealing_gives_the_same_bits(be, n):
+    """The optional XCD-aware dealing (`ptile_xcd`: one task queue per XCD - tile rows round-robin, or R x C groups per queue -
+    instead of ONE global ticket) changes WHO runs a task and in which order tasks are taken, never what a task computes: the
+    factor and the tile inverses are bit-identical, with one and with two workgroups per CU, and a not-PD matrix is still
+    reported (the queues must drain when the launch gives up on a pivot)."""
+    A = spd(n, n + 7)
+    _, info0, L0, W0 = potrf(be, A, 1)
+    assert info0 == 0
+    opts = dict(ptile_xcd=0, ptile_xcd_min_nt=56, ptile_grp_rows=8, ptile_grp_cols=4, ptile_single_max_nt=96)
+    try:
+        for mode, rows, cols, single in ((1, 8, 4, 96), (2, 8, 4, 96), (2, 4, 8, 0), (1, 8, 4, 0), (2, 2, 3, 96)):
+            be.set_options(ptile_xcd=mode, ptile_xcd_min_nt=0, ptile_grp_rows=rows, ptile_grp_cols=cols, ptile_single_max_nt=single)
+            _, info, L, W = potrf(be, A, 1)
+            assert info == 0 and np.array_equal(np.tril(L), np.tril(L0)) and np.array_equal(W, W0), (mode, rows, cols, single)
+        B = A.copy()
+        B[300, 300] = -1.0
+        be.set_options(ptile_xcd=2, ptile_grp_rows=8, ptile_grp_cols=4, ptile_single_max_nt=96)
+        rc, info, _, _ = potrf(be, B, 1)
+        assert rc == 1 and info == 301
+    finally:
+        be.set_options(**opts)
