@@ -72,7 +72,8 @@ GPK_API int64_t gpk_padded(int64_t n);
 /* gpk_set_option: the handle's tuning knobs (the library reads NOTHING from the environment), settable on a live handle:
  * "k5_split2_tile" (gpk_predict_var_inv_split2: 0 = the tallest of the 512 / 256 / 128 x 128 tiles that still comes in at
  * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256",
- * "trtri_levels", "gemm_small_tiles", "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
+ * "trtri_levels", "gemm_small_tiles" / "gemm_tiny_tiles" (launches of fewer 128 x 128 tiles than these - 1024 / 320 - run on 64 x 64 /,
+ * fp64 only, 32 x 32 tiles; bit-identical results), "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
  * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
  * up to this many tile columns (128 = always) the tiles under a diagonal tile follow its factorisation 16 columns at a time,
  * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 or 2 such tiles per column), "ptile_single_max_nt" (up to this many tile

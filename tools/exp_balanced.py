@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Tile GEMMs with varying k-range: static tile mapping against the balanced persistent schedule (gemm_balanced 0 / 1),
-same factor, same box: gpk_trtri and gpk_wtw per size; outputs must be bit-identical.
+"""Tile GEMMs with varying k-range, gpk_trtri and gpk_wtw per size, two settings of one option on the same factor and box; outputs
+must be bit-identical.  Default: static tile mapping against the balanced persistent schedule (gemm_balanced 0 / 1);
+OPT=gemm_tiny_tiles A=0 B=128: 64 x 64 tiles against 32 x 32 tiles for launches of fewer than 128 128-tiles.
     python tools/exp_balanced.py [sizes ...]"""
 import ctypes as C
 import os
@@ -18,6 +19,9 @@ def main():
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import get_backend
     be = get_backend(0)
+    OPT = os.environ.get("OPT", "gemm_balanced")
+    VA, VB = int(os.environ.get("A", "0")), int(os.environ.get("B", "1"))
+    restore = {"gemm_balanced": 1, "gemm_tiny_tiles": 64}.get(OPT, VB)
     sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096, 10112, 16384]
     p = lambda t: C.c_void_p(t.data_ptr())
     for n in sizes:
@@ -34,9 +38,9 @@ def main():
         work = be.empty(((n // 2 + 128) ** 2,), torch.float64)
         res, outs = {}, {}
         for mode in (0, 1, 0, 1):
-            be.check(be.lib.gpk_set_option(be.h, b"gemm_balanced", mode))
+            be.check(be.lib.gpk_set_option(be.h, OPT.encode(), VB if mode else VA))
             bt, bw = 1e30, 1e30
-            for _ in range(3):
+            for _ in range(5):
                 W.fill_(float("nan"))
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -50,10 +54,11 @@ def main():
             res[mode] = (bt, bw)
             outs[mode] = (W.clone(), Ki.clone()) if n <= 40000 else (W[:4096].clone(), Ki[-4096:].clone())
         same = bool(torch.equal(torch.nan_to_num(outs[0][0]), torch.nan_to_num(outs[1][0])) and torch.equal(outs[0][1].tril(), outs[1][1].tril()))
-        be.check(be.lib.gpk_set_option(be.h, b"gemm_balanced", 1))
+        be.check(be.lib.gpk_set_option(be.h, OPT.encode(), restore))
         fl = n ** 3 / 3
-        print(f"N={n:6d}  trtri static {res[0][0] * 1e3:8.3f} ms ({fl / res[0][0] / 1e12:5.1f} TF)  balanced {res[1][0] * 1e3:8.3f} ms "
-              f"({fl / res[1][0] / 1e12:5.1f} TF)   wtw static {res[0][1] * 1e3:8.3f} ms ({fl / res[0][1] / 1e12:5.1f} TF)  balanced "
+        la, lb = ("static", "balanced") if OPT == "gemm_balanced" else (f"{OPT}={VA}", f"{OPT}={VB}")
+        print(f"N={n:6d}  trtri {la} {res[0][0] * 1e3:8.3f} ms ({fl / res[0][0] / 1e12:5.1f} TF)  {lb} {res[1][0] * 1e3:8.3f} ms "
+              f"({fl / res[1][0] / 1e12:5.1f} TF)   wtw {la} {res[0][1] * 1e3:8.3f} ms ({fl / res[0][1] / 1e12:5.1f} TF)  {lb} "
               f"{res[1][1] * 1e3:8.3f} ms ({fl / res[1][1] / 1e12:5.1f} TF)   bit-identical {same}", flush=True)
         del K, W, Ki, work, winv, outs
 

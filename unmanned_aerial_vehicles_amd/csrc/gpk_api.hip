@@ -78,6 +78,7 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "trsm256") h->trsm256 = value;
   else if (n == "trtri_levels") h->trtri_levels = value;
   else if (n == "gemm_small_tiles") h->gemm_small_tiles = value;
+  else if (n == "gemm_tiny_tiles") h->gemm_tiny_tiles = value;
   else if (n == "gemm_balanced") h->gemm_balanced = value;
   else if (n == "gemm_balanced_max_tiles") h->gemm_balanced_max_tiles = value;
   else if (n == "k3_stream_min_np") h->k3_stream_min_np = value;

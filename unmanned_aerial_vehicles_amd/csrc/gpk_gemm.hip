@@ -620,7 +620,7 @@ int launch(gpk_handle h, const GemmArgs& g) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
         h->cus = cus;
       }
-      const long long resident = (long long)h->cus * (TS == 128 ? 2 : 4) / 64 * 64;
+      const long long resident = (long long)h->cus * (TS == 128 ? 2 : TS == 64 ? 4 : 8) / 64 * 64;
       p.balanced = 1;
       p.bal_wg = (int)(total < resident ? (total + 63) / 64 * 64 : resident);
       p.bal_tiles = (int)ntiles;
@@ -670,6 +670,10 @@ int gpk_gemm_tile(gpk_handle h, const GemmArgs& g) {
   if (g.nbatch > 0) t128 *= g.nbatch;                  // what counts is how many workgroups the launch has
   t128 *= h->batch;
   const bool aliased = g.C == g.A || g.C == g.B;
+  // (fp64 launches of fewer than gemm_tiny_tiles 128-tiles - the products of a 1000-row model: W^T W is 36 tiles - run on
+  // 32 x 32 tiles, four waves of 16 x 16: sixteen times the workgroups of the 128-tile form, a sixteenth of the k-loop's matrix
+  // work per wave - such a launch is bound by the time of its longest tile; the sum-of-squares and block-maximum epilogues keep 64)
+  if (!aliased && g.epilogue == 0 && t128 < h->gemm_tiny_tiles) return 32;
   return (!aliased && t128 < h->gemm_small_tiles) ? 64 : 128;
 }
 
@@ -691,7 +695,9 @@ int gpk_gemm(gpk_handle h, int dtype, const GemmArgs& g) {
   // the workgroups, a quarter of the work each; measured neutral at N = 65 536 and 5-35 % faster for the products of
   // N <= 8192 factorisations).  In-place launches (C aliasing an operand:
   // the 128-wide leaves of the triangular solves) rely on one tile covering everything it reads and keep 128.
-  const bool small = gpk_gemm_tile(h, g) == 64;
+  const int tile = gpk_gemm_tile(h, g);
+  const bool small = tile == 64;
+  if (tile == 32 && dtype == GPK_F64) return launch<double, 2, 32>(h, g);
   // wave rows per 128-tile workgroup (2 -> 256 threads, 4 -> 512 threads), per dtype; tuned on MI355X,
   // overridable through the options gemm_wm_f64 / gemm_wm_f32
   if (dtype == GPK_F64) {

@@ -176,8 +176,10 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ X, 
 // column tiles.  The row block's X is staged once; the X rows of the next column tile are fetched into
 // registers while the current tile is computed and stored, so the global-load latency of each tile is
 // hidden, and the 512-byte row segments of neighbouring tiles are written back to back by one workgroup.
-constexpr int GS = 8;
-template <typename T, bool NT>
+// (GS = 8 at the sizes where the launch fills the chip several times over; small matrices - the reference trains at N = 1000 ..
+// 10 000 - get shorter strips, down to one tile per workgroup, so that the launch has enough workgroups: N = 1024 is 24 strips of
+// 8 but 136 of 1.  The tiles themselves are computed identically whatever the strip length: bit-identical K.)
+template <typename T, bool NT, int GS>
 __global__ __launch_bounds__(256) void gram_strip_kernel(const T* __restrict__ X, long long N, int D, LsArr ls,
                                                          T sf2, T diag_add, T* __restrict__ K, long long ldk) {
   __shared__ __attribute__((aligned(16))) T xi[DCH * TS];
@@ -186,10 +188,10 @@ __global__ __launch_bounds__(256) void gram_strip_kernel(const T* __restrict__ X
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   // strip id -> (ti, g): tile row r has floor(r / GS) + 1 strips; rows [GS q, GS q + GS) hold GS (q + 1) strips
   const long long id = blockIdx.x;
-  long long q = (long long)((__builtin_sqrt(1.0 + 8.0 * (double)id / GS) - 1.0) * 0.5);   // (GS/2) q (q+1) <= id
-  while ((GS / 2) * (q + 1) * (q + 2) <= id) ++q;
-  while ((GS / 2) * q * (q + 1) > id) --q;
-  const long long rem_id = id - (GS / 2) * q * (q + 1);
+  long long q = (long long)((__builtin_sqrt(1.0 + 8.0 * (double)id / GS) - 1.0) * 0.5);   // GS q (q+1) / 2 <= id
+  while (GS * (q + 1) * (q + 2) / 2 <= id) ++q;
+  while (GS * q * (q + 1) / 2 > id) --q;
+  const long long rem_id = id - GS * q * (q + 1) / 2;
   const long long ti = GS * q + rem_id / (q + 1);
   const long long g = rem_id % (q + 1);
   const long long i0 = ti * TS;
@@ -718,13 +720,20 @@ extern "C" int gpk_gram(gpk_handle h, int dtype, const void* X, int64_t N, int D
   const dim3 block(256);
   // strip kernel for D <= 16 (one chunk of features); the tile-per-workgroup kernel otherwise
   const bool strip = D <= DCH;
-  long long nstrips = 0;
-  for (long long r = 0; r < nt; ++r) nstrips += r / GS + 1;
+  auto count = [&](int gs) { long long c = 0; for (long long r = 0; r < nt; ++r) c += r / gs + 1; return c; };
+  const int gs = count(8) >= 1024 ? 8 : count(2) >= 512 ? 2 : 1;     // strips per launch: enough workgroups for 256 CUs
+  const long long nstrips = count(gs);
   const dim3 grid((unsigned)(strip ? nstrips : tiles));
 #define GPK_GRAM_LAUNCH(T, NT)                                                                              \
   do {                                                                                                      \
-    if (strip)                                                                                              \
-      hipLaunchKernelGGL((gram_strip_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
+    if (strip && gs == 8)                                                                                   \
+      hipLaunchKernelGGL((gram_strip_kernel<T, NT, 8>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
+                         (T)sf2, (T)diag_add, (T*)K, (long long)ldk);                                       \
+    else if (strip && gs == 2)                                                                              \
+      hipLaunchKernelGGL((gram_strip_kernel<T, NT, 2>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
+                         (T)sf2, (T)diag_add, (T*)K, (long long)ldk);                                       \
+    else if (strip)                                                                                         \
+      hipLaunchKernelGGL((gram_strip_kernel<T, NT, 1>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l, \
                          (T)sf2, (T)diag_add, (T*)K, (long long)ldk);                                       \
     else                                                                                                    \
       hipLaunchKernelGGL((gram_sym_kernel<T, NT>), grid, block, 0, h->stream, (const T*)X, (long long)N, D, l,  \

@@ -36,6 +36,9 @@ struct gpk_context {
   int gemm_wm_f64 = 4;          // wave rows per GEMM workgroup (2 or 4); 4 = 512 threads, 4 waves/SIMD
   int gemm_wm_f32 = 4;
   int gemm_small_tiles = 1024;   // launches with fewer 128 x 128 tiles than this run on 64 x 64 tiles
+  int gemm_tiny_tiles = 320;     // fp64 launches with fewer 128 x 128 tiles than this run on 32 x 32 tiles (option gemm_tiny_tiles; 0: never);
+                                 // measured (profiles/r05_gemm_tiny_ab.log): W^T W at N = 1024 59 -> 33 us, 2048 108 -> 84 us, trtri 1024 117 -> 74 us;
+                                 // with 1024 the products of N >= 4096 lose
   int gemm_balanced = 1;         // launches whose tiles differ in k-range: balanced persistent tile schedule
   long long gemm_balanced_max_tiles = 32768;   // ... up to this many tiles per launch (all problems of a batch)
   int cus = 0;                   // compute units of the device (read once)
