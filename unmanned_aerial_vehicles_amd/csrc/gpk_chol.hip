@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict
   __shared__ double red[4];
   const int tid = threadIdx.x, b = blockIdx.x;
   // (status != null: the evaluation chain's status words ride along - the pivot failures of the nb problems and the one-launch
-  // factorisation's "gave up" flag next to the results, what was a launch of its own: gpk_status_enqueue)
+  // factorisation's "gave up" flag next to the results, what used to be a launch of its own)
   if (status && b == 0) {
     if (tid < nb) status[tid] = d_info[tid];
     if (tid == GPK_MAX_BATCH) status[tid] = gave_up ? *gave_up : 0;
@@ -845,22 +845,6 @@ int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info, int gave_up)
     h->err = buf;
     return GPK_NOT_PD;
   }
-  return GPK_OK;
-}
-
-namespace {
-__global__ void status_kernel(const int* __restrict__ d_info, const int* __restrict__ gave_up, int nb, int* __restrict__ out) {
-  const int t = threadIdx.x;
-  if (t < nb) out[t] = d_info[t];
-  if (t == GPK_MAX_BATCH) out[t] = gave_up ? *gave_up : 0;
-}
-}  // namespace
-
-int gpk_status_enqueue(gpk_handle h) {
-  hipLaunchKernelGGL(status_kernel, dim3(1), dim3(64), 0, h->stream, (const int*)h->d_info,
-                     h->ptile_launches > 0 ? (const int*)(h->d_ptile + GPK_PTILE_CTRL_INTS) : (const int*)nullptr, h->batch,
-                     reinterpret_cast<int*>(h->d_small + GPK_STATUS_OFF));
-  GPK_LAUNCH_CHECK(h);
   return GPK_OK;
 }
 

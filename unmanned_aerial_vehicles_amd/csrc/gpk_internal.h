@@ -136,16 +136,15 @@ void gpk_model_free(gpk_handle h);   // gpk_model.hip
 // the launches of gpk_potrf / gpk_lml_terms / gpk_lml_grad without their synchronisations (gpk_lml_eval)
 int gpk_potrf_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv);
 int gpk_potrf_finish(gpk_handle h, const int* hinfo_all, int* info, int gave_up = -1);
-// the pivot failures (h->batch ints) and the one-launch factorisation's "gave up" flag to ints [0, 8] of the status words
-// h->d_small + GPK_STATUS_OFF: a caller that reads d_small back anyway needs no other copy (gpk_lml_eval, gpk_lml_batched)
+// status words of an evaluation chain: ints [0, 8] of h->d_small + GPK_STATUS_OFF receive the pivot failures (h->batch ints) and the
+// one-launch factorisation's "gave up" flag (written by the terms launch: gpk_lml_terms_enqueue(..., with_status = 1))
 constexpr int GPK_STATUS_OFF = 480;
-int gpk_status_enqueue(gpk_handle h);
 // max |(float)W_ij| over the lower triangle per 128-row block, as float bits (first pass of gpk_split2_rows_f64)
 int gpk_tril_block_absmax_f64_enqueue(gpk_handle h, const double* W, int64_t n, int64_t ld, unsigned* out);
 int gpk_potrf_trtri_enqueue(gpk_handle h, double* A, int64_t Np, int64_t lda, double* winv, double* W, int64_t ldw, double* wt,
                             int* used);   // factor + inverse factor as one persistent launch (small matrices), or *used = 0
 int gpk_lml_terms_enqueue(gpk_handle h, const double* L, int64_t N, int64_t ldl, const double* Y, const double* alpha, int P,
-                          double* dout, int with_status = 0);   // with_status: + what gpk_status_enqueue writes, in the same launch
+                          double* dout, int with_status = 0);   // with_status: + the chain's status words, in the same launch
 int gpk_lml_grad_enqueue(gpk_handle h, const double* X, int64_t N, int D, const double* ls, double sf2, const double* alpha,
                          int P, const double* Kinv, int64_t ldk, double* dout);
 // B single-output evaluations on shared X as ONE chain with ONE synchronisation (gpk_lml_batched): the buffers hold the B
