@@ -76,7 +76,7 @@ GPK_API int64_t gpk_padded(int64_t n);
  * fp64 only, 32 x 32 tiles; bit-identical results), "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
  * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
  * up to this many tile columns (128 = always) the tiles under a diagonal tile follow its factorisation 16 columns at a time,
- * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 or 2 such tiles per column), "ptile_single_max_nt" (up to this many tile
+ * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 .. 8 such tiles per column; 8), "ptile_single_max_nt" (up to this many tile
  * columns (96) the launch keeps one workgroup per CU instead of two, 0 = always two), "ptile_inv_max_np" (gpk_lml_eval
  * with a gradient: up to this padded size (4608) the tiles of the inverse factor are tasks of the same launch, 0 = always the
  * level-by-level products of gpk_trtri; same values to rounding), "ptile_xcd" / "ptile_xcd_min_nt" / "ptile_grp_rows" /

@@ -167,12 +167,16 @@ def test_one_launch_handovers_on_and_off(be, n):
     assert np.abs(L1 - ref).max() < 1e-12 * scale and np.abs(L0 - ref).max() < 1e-12 * scale
     assert np.abs(L1 - L0).max() < 1e-12 * scale
     assert np.abs(W1 - W0).max() < 1e-11 * np.abs(W0).max()
-    be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", 1))
-    try:
-        _, info2, L2, W2 = potrf(be, A, 1)
-    finally:
-        be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", 2))
-    assert info2 == 0 and np.abs(np.tril(L2) - ref).max() < 1e-12 * scale
+    # any number of followers per column (default 8): a follower's tile goes through the forward substitution instead of the
+    # product with the finished inverse - the same factor to rounding whatever the count
+    for rows in (1, 2, 3, 5):
+        be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", rows))
+        try:
+            _, info2, L2, W2 = potrf(be, A, 1)
+        finally:
+            be.check(be.lib.gpk_set_option(be.h, b"ptile_prog_rows", 8))
+        assert info2 == 0 and np.abs(np.tril(L2) - ref).max() < 1e-12 * scale, rows
+        assert np.abs(W2 - W0).max() < 1e-11 * np.abs(W0).max(), rows
     # two resident workgroups per CU instead of one (the launch's form above 96 tile columns): who runs a task changes, what it
     # computes does not - the factor and the tile inverses are bit-identical
     be.check(be.lib.gpk_set_option(be.h, b"ptile_single_max_nt", 0))

@@ -55,7 +55,8 @@ struct gpk_context {
   int ptile_prog_max_nt = 128;  // ... up to this many tile columns the two tiles under a diagonal tile follow that tile's factorisation 16
                              // columns at a time instead of waiting for the whole inverse (0: never)
   int ptile_inv_max_np = 4608;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (0: never)
-  int ptile_prog_rows = 2;   // ... how many tiles under the diagonal one do so
+  int ptile_prog_rows = 8;   // ... how many tiles under the diagonal one do so (1 .. 8).  Measured (profiles/r05_ptile_followers_ab.log): N = 4096
+                             // 1.69 ms with none, 1.37 with one, 1.22 with two, 1.18 with four, 1.15 with eight, the same with twelve / sixteen
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
   int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU
@@ -123,7 +124,7 @@ struct gpk_context {
 int gpk_scratch(gpk_handle h, size_t bytes, void** out);
 
 // ---- one-launch tile Cholesky (gpk_ptile.hip) -----------------------------------------
-constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 4 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
+constexpr size_t GPK_PTILE_CTRL_INTS = 16 + 8 * 512 + 1024 + 10 * 8 * 512;   // ticket, abort, padding; GPK_MAX_BATCH x (Np / 128 <= 512) row
                                                         // counters; one pause word per CU; per tile row: 16-column steps of the diagonal
                                                         // tile / of the tile left of it / of the tile left of that one published so far
 // *used = 1: the launch was issued (the caller synchronises, reads info and calls gpk_potrf_ptile_check); 0: not served

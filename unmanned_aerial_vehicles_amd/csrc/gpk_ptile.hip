@@ -77,8 +77,8 @@ constexpr long long GPK_PTILE_TIMEOUT_TICKS = 400000000ll;   // 4 s of s_memreal
 constexpr int PAUSE_OFF = 16 + 8 * 512;       // ctrl ints: one word per compute unit (key < 1024)
 constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "block rows 0 .. v - 1 of L_jj and their W_bb are final"
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
-constexpr int YPROG_OFF = XPROG_OFF + 8 * 512; // ctrl ints: per tile row i, likewise for tile (i, i - 2)
-constexpr int WT_OFF = YPROG_OFF + 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
+constexpr int PT_MAX_FOLLOWERS = 8;           // ... and likewise for the tiles (i, i - 2) .. (i, i - 8): one region of 8 x 512 words per distance
+constexpr int WT_OFF = XPROG_OFF + PT_MAX_FOLLOWERS * 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
 #ifndef PT_LATE1
 #define PT_LATE1 4                            // diagonal task: block rows are published two steps late up to this step, one step late from it on
 #endif
@@ -97,7 +97,7 @@ struct PTParams {
   int nt, batch, ntasks;
   double* wt; long long strideWt;                  // non-null: the inverse factor's transpose W^T = L^-T by tiles as well (leading
                                                    // dimension lda): nt tasks per tile column instead of nt - column
-  int prog_rows;                                   // ... how many tiles under a diagonal tile do so (1 or 2)
+  int prog_rows;                                   // ... how many tiles under a diagonal tile do so (1 .. PT_MAX_FOLLOWERS)
   int prog;                                        // latency-bound launch: the sub-diagonal tiles follow their diagonal tiles step by step
   int* ctrl;                                       // [0] ticket counter, [1] abort; ready counters from ctrl + 16;
                                                    // "a critical diagonal task runs on this CU" words from ctrl + PAUSE_OFF;
@@ -340,7 +340,11 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     int* ready = p.ctrl + 16 + b * nt;
     int* wprog = p.ctrl + PROG_OFF + b * nt + j;     // diagonal tile j of problem b: 16-column steps published so far
     int* xprog = p.ctrl + XPROG_OFF + b * nt + i;    // tile (i, i - 1): 16-column blocks published so far
-    int* yprog = p.ctrl + YPROG_OFF + b * nt + i;    // tile (i, i - 2): likewise
+    // the word a follower (i, j), d = i - j rows under the diagonal, publishes its own blocks to - region d behind XPROG_OFF -, and the word that tells it about the blocks of the last tile of its own row panel, (i, j - 1): the tile of the follower
+    // one row further from the diagonal in the previous column, if there is one
+    const int dfol = i - j;
+    int* myprog = p.ctrl + XPROG_OFF + (min(max(dfol, 1), PT_MAX_FOLLOWERS) - 1) * (8 * 512) + b * nt + i;
+    const int* rowprog = (dfol >= 1 && dfol + 1 <= p.prog_rows) ? p.ctrl + XPROG_OFF + dfol * (8 * 512) + b * nt + i : nullptr;
     const long long lda = p.lda;
     double* Wt = p.wt ? reinterpret_cast<double*>(reinterpret_cast<char*>(p.wt) + (long long)b * p.strideWt) : nullptr;
     int* wtready = p.ctrl + WT_OFF + b * nt;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           } else {
             if (availk >= need) return true;
             if (tid == 0)
-              ctl[1] = poll_ktiles2(ready + i, i == j + 1 ? yprog : nullptr, ready + j, p.ctrl + XPROG_OFF + b * nt + j, j, need, abortp);
+              ctl[1] = poll_ktiles2(ready + i, rowprog, ready + j, p.ctrl + XPROG_OFF + b * nt + j, j, need, abortp);
             __syncthreads();
             const int v = ctl[1];
             __syncthreads();
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
               // wave's stores of column block CB - 1 have been acknowledged)
               asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
               __syncthreads();                                // image CB + 1 is complete, the poll's result is in
-              if (CB >= 1 && tid == 0) st_agent(i == j + 1 ? xprog : yprog, CB);
+              if (CB >= 1 && tid == 0) st_agent(myprog, CB);
               if (look) {
                 have = ctl[2 + (CB & 1)];
                 okc = min(okc, have);
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           wait_vm0();
           __syncthreads();
           if (tid == 0) {
-            st_agent(i == j + 1 ? xprog : yprog, 8);
+            st_agent(myprog, 8);
             st_agent(ready + i, j + 1);
             if (i == j + 1) pause_release(pausep, pause_tag);
           }
@@ -988,9 +992,9 @@ struct PrepParams {
 __global__ __launch_bounds__(256) void ptile_prepare_kernel(PrepParams p) {
   const long long r = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x;
-  if (r == 0 && b == 0) {
-    for (int e = tid; e < p.nctrl; e += 256) p.ctrl[e] = 0;
-    if (tid < p.ninfo) p.info[tid] = 0;
+  if (b == 0) {                                          // the control block, dealt over the launch's workgroups
+    for (long long e = r * 256 + tid; e < p.nctrl; e += (long long)gridDim.x * 256) p.ctrl[e] = 0;
+    if (r == 0 && tid < p.ninfo) p.info[tid] = 0;
   }
   if (tid < TS) {
     reinterpret_cast<double*>(reinterpret_cast<char*>(p.winv) + b * p.strideW)[r * TS + tid] = 0.0;
