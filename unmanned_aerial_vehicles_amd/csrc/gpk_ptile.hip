@@ -79,9 +79,13 @@ constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
 constexpr int PT_MAX_FOLLOWERS = 8;           // ... and likewise for the tiles (i, i - 2) .. (i, i - 8): one region of 8 x 512 words per distance
 constexpr int WT_OFF = XPROG_OFF + PT_MAX_FOLLOWERS * 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
+// Diagonal task, two schedule choices read off the sub-step stamps (profiles/r05_ptile_substamps.log, r05_ptile_defer_ab.log):
+#ifndef PT_DEFER
+#define PT_DEFER 1                            // the wave on the factoring wave's SIMD applies the previous block column behind the
+#endif                                        // step's first barrier: the 16 x 16 factor 4612 -> 3552 cycles
 #ifndef PT_LATE1
-#define PT_LATE1 4                            // diagonal task: block rows are published two steps late up to this step, one step late from it on
-#endif
+#define PT_LATE1 2                            // block rows are published two steps late up to this step, one step late from it on
+#endif                                        // (0 / 1 / 2 / 4 / 5 / never measured: N = 4096 1.157 / 1.155 / 1.149 / 1.171 / 1.180 / 1.269 ms)
 constexpr int XS = 18;                        // row stride (doubles) of a wave's 16 x 16 output staging block
 static_assert((22 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "forward substitution: two L images, the waves' W blocks and staging blocks");
 
@@ -836,30 +840,44 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           PT_SUB(2);
   #pragma unroll
           for (int s = 0; s < 8; ++s) S[s] = d4{0.0, 0.0, 0.0, 0.0};   // nothing of this wave's state is live here
-        } else if constexpr (JB > 0) {
-          constexpr int C = JB - 1;
-          const double* pc = lcol + (C & 1) * 8 * BLK;
-          const int hi = rw > C ? rw : 7;
-          const d4 nb = -S[C];
-          double an[4];
-  #pragma unroll
-          for (int t = 0; t < 4; ++t) an[t] = pc[(C + 1) * BLK + lr * BS + lq + 4 * t];
-          sfor<C + 1, 8>([&](auto xc) {
-            constexpr int X = decltype(xc)::value;
-            double ac[4];
-  #pragma unroll
-            for (int t = 0; t < 4; ++t) ac[t] = an[t];
-            if constexpr (X < 7) {
-  #pragma unroll
-              for (int t = 0; t < 4; ++t) an[t] = pc[(X + 1) * BLK + lr * BS + lq + 4 * t];
-            }
-            if (X <= hi && !(X == C + 1 && rw == C + 1)) {
-  #pragma unroll
-              for (int t = 0; t < 4; ++t) S[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], nb[t], S[X], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          });
+          // (clearing the slots behind the step's first barrier instead - the other waves wait at it - was measured: 1.22 against 1.17 ms)
         }
+        // Applying block column C = JB - 1.  The wave that shares its SIMD - and that SIMD's matrix pipe - with the factoring wave
+        // (block row 7 - JB: waves w and w + 4 sit on one SIMD) does NOT do it here, next to the factorisation, but behind the
+        // step's first barrier: its up to 28 MFMAs otherwise stand in front of the 14 dependent ones of the block routine (the
+        // routine took 4 600 cycles inside the kernel against 3 400 alone, profiles/r05_ptile_substamps.log), and in phase B that
+        // wave has one product and four stores to do.  (Not in step 3, where that wave owns the NEXT diagonal block.)
+        auto apply_prev = [&]() {
+          if constexpr (JB > 0) {
+            constexpr int C = JB - 1;
+            const double* pc = lcol + (C & 1) * 8 * BLK;
+            const int hi = rw > C ? rw : 7;
+            const d4 nb = -S[C];
+            double an[4];
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) an[t] = pc[(C + 1) * BLK + lr * BS + lq + 4 * t];
+            sfor<C + 1, 8>([&](auto xc) {
+              constexpr int X = decltype(xc)::value;
+              double ac[4];
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) ac[t] = an[t];
+              if constexpr (X < 7) {
+  #pragma unroll
+                for (int t = 0; t < 4; ++t) an[t] = pc[(X + 1) * BLK + lr * BS + lq + 4 * t];
+              }
+              if (X <= hi && !(X == C + 1 && rw == C + 1)) {
+  #pragma unroll
+                for (int t = 0; t < 4; ++t) S[X] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], nb[t], S[X], 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          }
+        };
+        // The factoring wave (block row JB) shares its SIMD with the wave of block row 7 - JB (waves w and w + 4): that wave's
+        // products would take every other issue slot from the serial 16 x 16 factor, so it runs them in phase B, when the
+        // factor is done (not in step 3, where the partner is the wave of the NEXT diagonal block and its state is needed first).
+        const bool deferred = PT_DEFER && JB > 0 && JB != 3 && rw == 7 - JB && rw != JB;
+        if (rw != JB && !deferred) apply_prev();
         // (the last step publishes the previous step's block row already here, a phase early: its stores are a whole sweep old,
         // and the tile under this one then has nothing but W_77 left to fetch when this task is done)
         if constexpr (JB == 7) {
@@ -874,6 +892,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         if (rw == JB + 1) PT_SUB(8);
         // ---- phase B: S[JB] <- W_bb * S[JB]: below the diagonal block that is L(rw, JB)^T, in the columns of the inverse
         //      W(JB, rw); the wave of the diagonal block itself takes W_bb as it stands
+        if (deferred) apply_prev();
         if (rw == JB) {
   #pragma unroll
           for (int t = 0; t < 4; ++t) S[JB][t] = wd[JB * BLK + lr * BS + lq + 4 * t];
@@ -926,9 +945,9 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
         // more.)  The last step publishes a phase early instead (above), and the end of the task everything.
         // (p.prog = 0: a launch without the 16-column hand-overs - the A/B switch ptile_prog_max_nt.)
         // (with W^T in the launch the waves of the inverse columns issue four more stores per step: 8, the factoring wave 12)
-        // From step PT_LATE1 on the lag is ONE step: by then the previous column's tiles are out and an acknowledgement takes
-        // ~2.5 us, less than a step - and the tile under this one, which cannot start a block row before it is published, is one
-        // step closer behind when this task ends.
+        // From step PT_LATE1 on the lag is ONE step: the tile under this one, which cannot start a block row before it is
+        // published, is one step closer behind when this task ends - worth more than the stalls it costs now that eight tiles
+        // follow the diagonal task (never one step late: 1.27 ms at N = 4096; from step 2 on: 1.15 ms).
         constexpr bool ONE = JB >= PT_LATE1;
         if (p.prog) {
           if (Wt) {
