@@ -16,6 +16,8 @@ def main():
     import torch
     from unmanned_aerial_vehicles_amd import _lib
     from unmanned_aerial_vehicles_amd.device import get_backend
+    from tools import gpk_opts
+    gpk_opts.install()                                     # GPK_OPTS="name=value,..."
     be = get_backend(0)
     sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 16384]
     p = lambda t: C.c_void_p(t.data_ptr())

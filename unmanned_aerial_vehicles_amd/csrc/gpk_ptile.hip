@@ -323,6 +323,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
     if (p.list) {
       const int e = p.list[16 + task];
       i = e & 511; j = (e >> 9) & 511; b = e >> 18;
+      if (p.trace && tid == 0) p.trace[(long long)task * 16 + 15] = e;      // (a listed launch: which tile this was)
     } else {
       b = task % p.batch;
       const long long tt = task / p.batch;
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
             __syncthreads();
             if (v < 0) return false;
             availk = min(v, nkt);
+            if (availk >= nkt) PT_STAMP(11);
             return true;
           }
         };
