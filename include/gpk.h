@@ -74,7 +74,7 @@ GPK_API int64_t gpk_padded(int64_t n);
  * least 512 tiles, 1 = always 128 x 128, 2 = 512 x 128 whenever Np % 512 == 0), "k5_super", "small_path", "trsm256",
  * "trtri_levels", "gemm_small_tiles" / "gemm_tiny_tiles" (launches of fewer 128 x 128 tiles than these - 1024 / 320 - run on 64 x 64 /,
  * fp64 only, 32 x 32 tiles; bit-identical results), "k3_stream_min_np", "ptile" (gpk_potrf: 1 = the one-launch tile factorisation of
- * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (16384), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
+ * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (24576), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
  * up to this many tile columns (128 = always) the tiles under a diagonal tile follow its factorisation 16 columns at a time,
  * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 .. 8 such tiles per column; 8), "ptile_single_max_nt" (up to this many tile
  * columns (96) the launch keeps one workgroup per CU instead of two, 0 = always two), "ptile_inv_max_np" (gpk_lml_eval

@@ -147,6 +147,39 @@ def test_one_launch_repeatable_and_large(be):
     assert np.abs(Wa - W0).max() < 1e-11 * np.abs(W0).max()
 
 
+def test_one_launch_above_16384_rows(be):
+    """20 480 rows (160 tile columns: two workgroups per CU, whole-tile hand-overs) as ONE launch against the recursion whose halves
+    are launches of 10 240 rows (ptile_max_np = 16384, the default until round 5; 24 576 now): the same factor to rounding, compared on the
+    device; L L^T = A on sampled entries."""
+    import torch
+    from unmanned_aerial_vehicles_amd import _lib
+    n = 20480
+    X = torch.as_tensor(np.random.default_rng(3).standard_normal((n, 9)), device=be.device)
+    ls = np.full(9, 2.0)
+    K0 = be.empty((n, n), torch.float64)
+    be.check(be.lib.gpk_gram(be.h, _lib.GPK_F64, _p(X), n, 9, ls.ctypes.data_as(_lib._dp), 1.0, 0.1001, _p(K0), n))
+    winv = be.empty((n, 128), torch.float64)
+    info = C.c_int(0)
+    out = []
+    try:
+        for max_np in (24576, 16384):
+            be.set_options(ptile_max_np=max_np)
+            K = K0.clone()
+            assert be.lib.gpk_potrf(be.h, _p(K), n, n, _p(winv), C.byref(info)) == 0 and info.value == 0
+            out.append((torch.tril(K), winv.clone()))
+    finally:
+        be.set_options(ptile_max_np=24576)
+    (L1, W1), (L2, W2) = out
+    scale = float(L2.abs().max())
+    assert float((L1 - L2).abs().max()) < 1e-11 * scale
+    assert float((W1 - W2).abs().max()) < 1e-10 * float(W2.abs().max())
+    rows = torch.as_tensor(np.random.default_rng(0).integers(0, n, 64), device=be.device)
+    cols = torch.as_tensor(np.random.default_rng(1).integers(0, n, 64), device=be.device)
+    got = (L1[rows] * L1[cols]).sum(1)
+    want = K0[torch.maximum(rows, cols), torch.minimum(rows, cols)]
+    assert float((got - want).abs().max()) < 1e-11
+
+
 @pytest.mark.parametrize("n", [640, 1000, 2048, 3000])
 def test_one_launch_handovers_on_and_off(be, n):
     """The 16-column hand-overs (the two tiles under a diagonal tile follow its factorisation block row by block row -

@@ -51,7 +51,8 @@ struct gpk_context {
   int k5_split2_tile = 0;    // fp16 x 2 variance launch: 0 = the tallest tile (512 / 256 / 128 x 128) that still comes in >= 512
                              // tiles; 1 = always 128 x 128; 2 = 512 x 128 whenever Np % 512 == 0
   int ptile = 1;             // gpk_potrf: one persistent launch (gpk_ptile.hip) for 512 <= Np <= ptile_max_np
-  int ptile_max_np = 16384;
+  int ptile_max_np = 24576;  // (above, the recursion: halves that are one launch each + GEMMs.  One launch against that at 20 480 rows 46.7 / 48.6 ms,
+                             // 24 576 78.6 / 79.2, 32 768 179.4 / 172.5, 40 960 347.4 / 340.6: profiles/r05_ptile_large.log; 16 384 until round 5)
   int ptile_prog_max_nt = 128;  // ... up to this many tile columns the two tiles under a diagonal tile follow that tile's factorisation 16
                              // columns at a time instead of waiting for the whole inverse (0: never)
   int ptile_inv_max_np = 4608;  // gpk_lml_eval: up to this padded size the inverse factor's tiles are tasks of the same launch (0: never)
