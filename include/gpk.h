@@ -77,7 +77,8 @@ GPK_API int64_t gpk_padded(int64_t n);
  * gpk_ptile.hip for 512 <= Np <= "ptile_max_np" (24576), 0 = the recursive launch chain), "ptile_prog_max_nt" (that launch:
  * up to this many tile columns (128 = always) the tiles under a diagonal tile follow its factorisation 16 columns at a time,
  * 0 = they wait for the whole inverse tile), "ptile_prog_rows" (1 .. 8 such tiles per column; 8), "ptile_single_max_nt" (up to this many tile
- * columns (96) the launch keeps one workgroup per CU instead of two, 0 = always two), "ptile_inv_max_np" (gpk_lml_eval
+ * columns (96) the launch keeps one workgroup per CU instead of two, 0 = always two), "ptile_sr" / "ptile_sr_max_nt" (1: launches of up to
+ * that many tile columns (36) run the 256-register build with two k-tiles in flight; bit-identical factors), "ptile_inv_max_np" (gpk_lml_eval
  * with a gradient: up to this padded size (4608) the tiles of the inverse factor are tasks of the same launch, 0 = always the
  * level-by-level products of gpk_trtri; same values to rounding), "ptile_xcd" / "ptile_xcd_min_nt" / "ptile_grp_rows" /
  * "ptile_grp_cols" (XCD-aware dealing of that launch's tasks: 0 = one global ticket counter (default), 1 = one queue per XCD with

@@ -218,6 +218,14 @@ def test_one_launch_handovers_on_and_off(be, n):
     finally:
         be.check(be.lib.gpk_set_option(be.h, b"ptile_single_max_nt", 96))
     assert info3 == 0 and np.array_equal(np.tril(L3), L1) and np.array_equal(W3, W1)
+    # the 128-register build of the launch (the small launches run a 256-register build with two k-tiles in flight in the
+    # off-diagonal k-loops): the same arithmetic in the same order - bit-identical
+    be.set_options(ptile_sr=0)
+    try:
+        _, info4, L4, W4 = potrf(be, A, 1)
+    finally:
+        be.set_options(ptile_sr=1)
+    assert info4 == 0 and np.array_equal(np.tril(L4), L1) and np.array_equal(W4, W1)
 
 
 @pytest.mark.parametrize("n", [640, 2048, 3000])

@@ -96,6 +96,8 @@ extern "C" int gpk_set_option(gpk_handle h, const char* name, int value) {
   else if (n == "ptile_grp_rows") h->ptile_grp_rows = value;
   else if (n == "ptile_grp_cols") h->ptile_grp_cols = value;
   else if (n == "ptile_xcd_min_nt") h->ptile_xcd_min_nt = value;
+  else if (n == "ptile_sr") h->ptile_sr = value;
+  else if (n == "ptile_sr_max_nt") h->ptile_sr_max_nt = value;
   else if (n == "ptile_prog_rows") h->ptile_prog_rows = value >= 8 ? 8 : value >= 1 ? value : 1;
   else { h->err = "bad argument: unknown option " + n; return GPK_BAD_ARG; }
   return GPK_OK;

@@ -60,6 +60,8 @@ struct gpk_context {
                              // 1.69 ms with none, 1.37 with one, 1.22 with two, 1.18 with four, 1.15 with eight, the same with twelve / sixteen
   int* d_ptile = nullptr;    // its ticket counter, abort word and per-tile-row progress counters
   int ptile_slots = 512;     // workgroups that fit the device at two per CU
+  int ptile_sr = 1, ptile_sr_max_nt = 36;   // ... and up to this many tile columns the 256-register build (two k-tiles in flight in the off-diagonal
+                             // k-loops: gpk_ptile.hip, SR); ptile_sr = 0: the 128-register build for everything
   int ptile_single_max_nt = 96;   // ... up to this many tile columns the launch keeps ONE workgroup per CU
   int ptile_xcd = 0;         // 1: one task queue per XCD, tile rows dealt round-robin; 2: groups of rows x columns tiles per queue; 0: ONE
                              // global ticket counter - the default: measured, neither dealing raises the L2 hit rate (the tasks of an XCD

@@ -276,7 +276,12 @@ __device__ __noinline__ int take_task(const int* list, int* ctrl, int home) {
 #endif
 #define PT_STAMP(k) do { if (p.trace && tid == 0) p.trace[(long long)task * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
-__global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
+// SR: a second build for the small launches (up to ptile_sr_max_nt tile columns, one resident workgroup per CU): two waves per
+// SIMD, 256 registers per lane.  The same tasks, the same arithmetic in the same order (bit-identical factors); what the
+// registers buy is a second k-tile in flight in the off-diagonal k-loops (below).  Measured against the 128-register build:
+// N = 512 .. 2048 2 - 3 % faster, 4096 1 %, 5120 equal, 6144 - 8192 1 - 3 % slower (profiles/r05_ptile_sr_ab.log).
+template <bool SR>
+__global__ __launch_bounds__(NT, SR ? 2 : 4) void ptile_potrf_kernel(PTParams p) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   int* ctl = reinterpret_cast<int*>(lds + CTL_OFF);
   const int tid = threadIdx.x;
@@ -521,6 +526,77 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
             return true;
           }
         };
+        // the products of one k-tile: rows of panel j (la) against this wave's rows of panel i (lb)
+        auto mma = [&](const char* la, const char* lb) {
+  #pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            dv2 bf = *reinterpret_cast<const dv2*>(lb + (16 * rw + lr) * ROWB + (4 * lq + 2 * hh) * 8);
+            bf.x = -bf.x; bf.y = -bf.y;
+            sfor<0, 2>([&](auto gc) {
+              constexpr int G = decltype(gc)::value;
+              dv2 af[4];
+  #pragma unroll
+              for (int x = 0; x < 4; ++x)
+                af[x] = *reinterpret_cast<const dv2*>(la + (16 * (4 * G + x) + lr) * ROWB + (4 * lq + 2 * hh) * 8);
+              sfor<0, 4>([&](auto xc) {
+                constexpr int KB = 4 * G + decltype(xc)::value;
+                S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].x, bf.x, S[KB], 0, 0, 0);
+                S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].y, bf.y, S[KB], 0, 0, 0);
+              });
+            });
+          }
+        };
+        if constexpr (SR && !PROG) {
+          // TWO k-tiles in flight, in two register sets that take turns (no copies: a copy would wait for the younger set): a
+          // k-tile issued in iteration kt is written to LDS in iteration kt + 2 - two k-tiles of matrix work (3.4 us) to arrive
+          // instead of one (1.7).  Set A (ra, rb): the odd k-tiles, set B (qa, qb): the even ones.  Worth 2 - 3 % of a launch
+          // inside this build (profiles/r05_ptile_sr_ab.log) - not more: with the arithmetic taken out a launch takes the same
+          // time with one k-tile in flight and with two (N = 8192: 2.99 / 3.02 ms of 3.83; profiles/r05_ptile_data_path.log) -
+          // what bounds these launches is the order of the tasks, not how fast one of them streams.
+          // The loop runs in STRETCHES without a poll inside: the compiler's wait-count pass gives up on exact counts in a loop
+          // that contains a spin loop with loads of its own (every LDS write then waits for vmcnt(0) - the younger set too; seen in
+          // the assembly), so the availability of everything a stretch issues is settled in front of it, and the use of all four
+          // registers there starts the stretch from "nothing in flight".  (The followers keep the loop below: they take their
+          // last tile column k-tile by k-tile as it is published and cannot wait for three k-tiles ahead.)
+          if (!need_kt(min(3, nkt))) return false;
+          V16 ra[2], rb[2], qa[2], qb[2];
+          load_ktile(pj, voff, ra);
+          load_ktile(pi, voff, rb);
+          store_ktile(lds, tk, ra);
+          store_ktile(lds + OPB, tk, rb);
+          {
+            const int k1 = min(1, nkt - 1), k2 = min(2, nkt - 1);
+            load_ktile(pj + k1 * (BK * 8), voff, ra);
+            load_ktile(pi + k1 * (BK * 8), voff, rb);
+            load_ktile(pj + k2 * (BK * 8), voff, qa);
+            load_ktile(pi + k2 * (BK * 8), voff, qb);
+          }
+          __syncthreads();
+          auto step = [&](int kt, auto curc, V16 (&xa)[2], V16 (&xb)[2]) {
+            constexpr int cur = decltype(curc)::value;
+            store_ktile(lds + (cur ^ 1) * 2 * OPB, tk, xa);
+            store_ktile(lds + (cur ^ 1) * 2 * OPB + OPB, tk, xb);
+            const int kn = min(kt + 3, nkt - 1);
+            load_ktile(pj + (long long)kn * (BK * 8), voff, xa);
+            load_ktile(pi + (long long)kn * (BK * 8), voff, xb);
+            mma(lds + cur * 2 * OPB, lds + cur * 2 * OPB + OPB);
+            __syncthreads();
+          };
+          int kt = 0;
+  #pragma unroll 1
+          while (kt < nkt) {
+            if (!need_kt(min(kt + 4, nkt))) return false;          // k-tile kt + 3, the next one to be issued, is final (or all are)
+            const int ke = 8 * avail >= nkt ? nkt : 8 * avail - 3;   // iterations < ke issue final k-tiles only
+            asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(qa[0]), "+v"(qa[1]), "+v"(qb[0]), "+v"(qb[1]));
+            if (kt & 1) { step(kt, IC<1>{}, qa, qb); ++kt; }
+  #pragma unroll 1
+            for (; kt + 1 < ke; kt += 2) {
+              step(kt, IC<0>{}, ra, rb);
+              step(kt + 1, IC<1>{}, qa, qb);
+            }
+            if (kt < ke) { step(kt, IC<0>{}, ra, rb); ++kt; }
+          }
+        } else {
         if (!need_kt(min(2, nkt))) return false;
         int pause_seen = 0;
         V16 ra[2], rb[2];
@@ -546,25 +622,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
           }
           load_ktile(pj + (long long)kn * (BK * 8), voff, ra);
           load_ktile(pi + (long long)kn * (BK * 8), voff, rb);
-          const char* la = lds + cur * 2 * OPB;                     // rows of panel j
-          const char* lb = la + OPB;                                // rows of panel i (the same rows in a diagonal task)
-  #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            dv2 bf = *reinterpret_cast<const dv2*>(lb + (16 * rw + lr) * ROWB + (4 * lq + 2 * hh) * 8);
-            bf.x = -bf.x; bf.y = -bf.y;
-            sfor<0, 2>([&](auto gc) {
-              constexpr int G = decltype(gc)::value;
-              dv2 af[4];
-  #pragma unroll
-              for (int x = 0; x < 4; ++x)
-                af[x] = *reinterpret_cast<const dv2*>(la + (16 * (4 * G + x) + lr) * ROWB + (4 * lq + 2 * hh) * 8);
-              sfor<0, 4>([&](auto xc) {
-                constexpr int KB = 4 * G + decltype(xc)::value;
-                S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].x, bf.x, S[KB], 0, 0, 0);
-                S[KB] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[KB - 4 * G].y, bf.y, S[KB], 0, 0, 0);
-              });
-            });
-          }
+          mma(lds + cur * 2 * OPB, lds + cur * 2 * OPB + OPB);
           __syncthreads();
           // A critical task (the diagonal task of column c, or the tile below it) runs on this CU and has raised c + 1: stand
           // still - but only a task of column >= c does, which nothing on the critical task's dependency chain waits for.
@@ -575,6 +633,7 @@ __global__ __launch_bounds__(NT, 4) void ptile_potrf_kernel(PTParams p) {
             pause_seen = 0;
             __syncthreads();
           }
+        }
         }
         }
       }
@@ -1153,7 +1212,9 @@ int gpk_potrf_ptile(gpk_handle h, double* A, int64_t Np, int64_t lda, double* wi
   int slots = nt <= h->ptile_single_max_nt ? h->ptile_slots / 2 : h->ptile_slots;
   if (h->ptile_slots_override > 0) slots = h->ptile_slots_override;      // (experiments: option "ptile_slots")
   const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
-  hipLaunchKernelGGL(ptile_potrf_kernel, dim3(grid), dim3(NT), 0, h->stream, p);
+  // (the small launches: the 256-register build)
+  if (h->ptile_sr && nt <= h->ptile_sr_max_nt && slots <= h->ptile_slots / 2) hipLaunchKernelGGL(ptile_potrf_kernel<true>, dim3(grid), dim3(NT), 0, h->stream, p);
+  else hipLaunchKernelGGL(ptile_potrf_kernel<false>, dim3(grid), dim3(NT), 0, h->stream, p);
   GPK_LAUNCH_CHECK(h);
   ++h->ptile_launches;
   *used = 1;
