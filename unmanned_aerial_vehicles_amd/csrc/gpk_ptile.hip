@@ -80,6 +80,9 @@ constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-
 constexpr int PT_MAX_FOLLOWERS = 8;           // ... and likewise for the tiles (i, i - 2) .. (i, i - 8): one region of 8 x 512 words per distance
 constexpr int WT_OFF = XPROG_OFF + PT_MAX_FOLLOWERS * 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
 // Diagonal task, two schedule choices read off the sub-step stamps (profiles/r05_ptile_substamps.log, r05_ptile_defer_ab.log):
+#ifndef PT_LINE_STORES
+#define PT_LINE_STORES 1
+#endif
 #ifndef PT_DEFER
 #define PT_DEFER 1                            // the wave on the factoring wave's SIMD applies the previous block column behind the
 #endif                                        // step's first barrier: the 16 x 16 factor 4612 -> 3552 cycles
@@ -93,6 +96,7 @@ static_assert(4 * OPB <= CTL_OFF, "staging buffers");
 static_assert(36 * BLK * 8 <= CTL_OFF, "W_jj image");
 static_assert(TS * OS * 8 <= CTL_OFF, "output staging image");
 static_assert((8 + 16) * BLK * 8 <= CTL_OFF, "leaf work area");
+static_assert((24 * BLK + 8 * 16 * XS) * 8 <= CTL_OFF, "leaf work area + the waves' staging blocks for the rows of W_jj^T");
 
 struct PTParams {
   double* A; long long lda; long long strideA;     // strides between the problems of a batch, in bytes
@@ -123,6 +127,7 @@ __device__ __forceinline__ void sfor(F&& f) {
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // The thread index again, opaque to the optimiser: every section of the kernel derives its per-lane offsets from a
 // fresh copy, so that they live for that section only.  (Derived from ONE tid they are loop invariants of the task
 // loop; the register allocator then spills them around the register-hungry sections and reloads them inside the
@@ -872,6 +877,9 @@ __global__ __launch_bounds__(NT, SR ? 2 : 4) void ptile_potrf_kernel(PTParams p)
       double* wd = reinterpret_cast<double*>(lds);                  // wd[b][r][c] = W_bb[c][r]
       double* lcol = wd + 8 * BLK;                                  // two block columns of L: lcol[buf][block row]
       double* Wj = Wv + (long long)j * TS * TS;
+      const __amdgpu_buffer_rsrc_t rtile = __builtin_amdgcn_make_buffer_rsrc(Atile, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rwt =
+          __builtin_amdgcn_make_buffer_rsrc(Wt ? Wt + (long long)j * TS * (lda + 1) : Atile, 0, 0x7fffffff, 0x00020000);
       int* info = p.info + b;
       __syncthreads();                                              // the k-loop's last reads of the staging buffers
       sfor<1, 8>([&](auto kc) {                                     // the blocks right of the diagonal are not part of the task
@@ -976,18 +984,48 @@ __global__ __launch_bounds__(NT, SR ? 2 : 4) void ptile_potrf_kernel(PTParams p)
           }
           // (write-through, as W below: the task of the tile under this one reads L_jj and the W_bb block row by block row
           // while the factorisation is still running)
+#if PT_LINE_STORES
+          // Whole 128-byte lines: from the accumulators a store instruction writes 32 bytes of each of 16 rows - partial lines,
+          // which the memory side turns into read-modify-writes (their acknowledgement took 3.6 us where a task that writes
+          // whole rows sees 1.2: profiles/r05_ptile_substamps.log) - so the block is read back from the image this wave has
+          // just written (same-wave LDS traffic is ordered), eight rows of 128 bytes per instruction, 16 bytes per lane.
+          {
+            const int prow = lane >> 3, pcc = lane & 7;
+  #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const double* src = lc + rw * BLK + (8 * u + prow) * BS + 2 * pcc;
+              const dv2 d = {src[0], src[1]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(V16, d), rtile,
+                                                     (unsigned)(((long long)(16 * rw + 8 * u + prow) * lda + 16 * JB + 2 * pcc) * 8), 0, 16);
+            }
+          }
+#else
           double* dst = Atile + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
   #pragma unroll
           for (int t = 0; t < 4; ++t) __hip_atomic_store(dst + 4 * t, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         } else {
           double* dst = Wj + (long long)(16 * JB + lq) * TS + 16 * rw + lr;
   #pragma unroll
           for (int t = 0; t < 4; ++t)
             __hip_atomic_store(dst + 4 * t * TS, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (Wt) {                                                 // W_jj^T, the diagonal tile of W^T: entry (16 rw + n, 16 JB + q + 4 t)
+#if PT_LINE_STORES
+            // (the same, through this wave's own staging block: rows of W_jj^T)
+            double* stg = wd + 24 * BLK + wave * (16 * XS);
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) stg[lr * XS + lq + 4 * t] = S[JB][t];
+            const int prow = lane >> 3, pcc = lane & 7;
+  #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const V16 v = *reinterpret_cast<const V16*>(stg + (8 * u + prow) * XS + 2 * pcc);
+              __builtin_amdgcn_raw_buffer_store_b128(v, rwt, (unsigned)(((long long)(16 * rw + 8 * u + prow) * lda + 16 * JB + 2 * pcc) * 8), 0, 16);
+            }
+#else
             double* dt = Wt + (long long)j * TS * (lda + 1) + (long long)(16 * rw + lr) * lda + 16 * JB + lq;
   #pragma unroll
             for (int t = 0; t < 4; ++t) __hip_atomic_store(dt + 4 * t, S[JB][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
           }
           if (rw == JB) {                                           // L_bb: lower triangle only (the tile's upper part stays)
             double* dl = Atile + (long long)(16 * JB + lr) * lda + 16 * JB + lq;
@@ -1011,23 +1049,30 @@ __global__ __launch_bounds__(NT, SR ? 2 : 4) void ptile_potrf_kernel(PTParams p)
         // follow the diagonal task (never one step late: 1.27 ms at N = 4096; from step 2 on: 1.15 ms).
         constexpr bool ONE = JB >= PT_LATE1;
         if (p.prog) {
+          // stores per step: a wave of the factor's rows NL, a wave of the inverse's columns 4 (+ NT with W^T), the factoring wave
+          // 8 (+ NT); a wave waits until only this step's (ONE) or this and the previous step's stores are outstanding
+          constexpr int NL = PT_LINE_STORES ? 2 : 4, NT_ = PT_LINE_STORES ? 2 : 4;
           if (Wt) {
             if (ONE) {
-              if (rw > JB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-              else if (rw == JB) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-              else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              if (rw > JB) wait_vm<NL>();
+              else if (rw == JB) wait_vm<8 + NT_>();
+              else wait_vm<4 + NT_>();
             } else {
-              if (rw > JB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-              else if (rw == JB - 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-              else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+              if (rw > JB) wait_vm<2 * NL>();
+              else if (rw == JB) wait_vm<NL + 8 + NT_>();
+              else if (rw == JB - 1) wait_vm<8 + NT_ + 4 + NT_>();
+              else wait_vm<2 * (4 + NT_)>();
             }
           } else {
             if (ONE) {
-              if (rw == JB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-              else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+              if (rw > JB) wait_vm<NL>();
+              else if (rw == JB) wait_vm<8>();
+              else wait_vm<4>();
             } else {
-              if (rw == JB || rw == JB - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-              else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              if (rw > JB) wait_vm<2 * NL>();
+              else if (rw == JB) wait_vm<NL + 8>();
+              else if (rw == JB - 1) wait_vm<12>();
+              else wait_vm<8>();
             }
           }
         }
