@@ -735,12 +735,22 @@ __global__ __launch_bounds__(NT, SR ? 2 : 4) void ptile_potrf_kernel(PTParams p)
               double* stg = wl + 22 * BLK + wave * (16 * XS);
   #pragma unroll
               for (int t = 0; t < 4; ++t) stg[qr * XS + qq + 4 * t] = S[CB][t];
+#if PT_LINE_STORES
+              // (eight whole 128-byte rows per store instruction - not two 16-byte pieces of every row in each of two)
+              const int ln = tq & 63, prow = ln >> 3, pcol = 2 * (ln & 7);
+  #pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const V16 v = *reinterpret_cast<const V16*>(stg + (8 * u + prow) * XS + pcol);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rx, (unsigned)(((long long)(16 * wave + 8 * u + prow) * lda + 16 * CB + pcol) * 8), 0, 16);
+              }
+#else
               const int ln = tq & 63, prow = ln >> 2, pcol = 4 * (ln & 3);
   #pragma unroll
               for (int u = 0; u < 2; ++u) {
                 const V16 v = *reinterpret_cast<const V16*>(stg + prow * XS + pcol + 2 * u);
                 __builtin_amdgcn_raw_buffer_store_b128(v, rx, (unsigned)(((long long)(16 * wave + prow) * lda + 16 * CB + pcol + 2 * u) * 8), 0, 16);
               }
+#endif
             }
             if constexpr (CB < 7) {
               // ---- the next step: its L blocks go into the other image, then wait for W_(CB+1) (and with it L row CB + 2)
