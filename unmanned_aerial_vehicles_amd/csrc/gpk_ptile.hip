@@ -32,7 +32,9 @@
 // off-diagonal tiles, W_jj) is written with sc1 (write-through) stores and read with sc1 loads; each storing wave waits
 // for its stores (s_waitcnt vmcnt(0)), a workgroup barrier follows, and ONE lane raises the counter with an sc1 store;
 // consumers poll it with sc1 loads.  A tile is written exactly once and never read before it is final, so no XCD can
-// hold a stale copy.  L_jj (nobody reads it inside the launch) uses plain stores.
+// hold a stale copy.  (Keeping a launch on ONE XCD and handing over through its L2 with plain stores was measured: the same
+// time - profiles/r05_ptile_one_xcd_ab.log.  What does matter is the SHAPE of a store: whole 128-byte lines per instruction,
+// not 32-byte pieces of sixteen lines - the diagonal task and the followers stage their blocks through LDS for that.)
 // Every spin loop gives up after GPK_PTILE_TIMEOUT_TICKS of the 100 MHz real-time counter and raises an abort word that
 // every other loop polls: the grid always drains.
 //
@@ -41,9 +43,10 @@
 // and each arrow through whole tiles costs a write-through acknowledgement, a flag and 64-128 KB of freshly written lines.
 // Instead the diagonal task publishes "block rows < v of L_jj and their 16 x 16 inverses W_bb are final" as it goes
 // (wprog; its waves count their own stores - vector memory operations complete in order - so the acknowledgement wait is
-// taken one or two steps late and does not stall); the tasks of the two tiles under it (a third instantiation of the task
-// body, PROG) solve  X L_jj^T = X^  by forward substitution behind it, block row by block row, and publish every finished
-// 16-column block of their own tile (xprog / yprog); and whoever multiplies those tiles next takes them k-tile by k-tile
+// taken one or two steps late and does not stall); the tasks of up to EIGHT tiles under it (p.prog_rows; a third instantiation
+// of the task body, PROG) solve  X L_jj^T = X^  by forward substitution behind it, block row by block row, and publish every
+// finished 16-column block of their own tile (one progress word per tile row and distance from the diagonal); and whoever
+// multiplies those tiles next takes them k-tile by k-tile
 // (poll_ktiles).  When a diagonal task is done, the tile under it has one fetch and one block product left, and when that
 // tile is done the next diagonal task has one k-tile left.  Deadlock freedom is unchanged: every wait is still for a task
 // earlier in the list.
@@ -52,6 +55,11 @@
 // same list (PTParams::wt: tile (i, j), i < j, = -(sum_{k=i}^{j-1} W^T(i,k) L(j,k)^T) W_jj^T - the off-diagonal task on another
 // pair of panels; they run in the part of the chip the diagonal chain leaves idle), and the residency: ONE workgroup per CU
 // up to ptile_single_max_nt tile columns (every link of the chain is shorter on a CU nobody shares), two above.
+// Round 5: eight followers per column instead of two; the diagonal task's 16-column step re-scheduled from its sub-step stamps
+// (deferred apply, one-step-late publication from step 2, whole-line stores); a second, 256-register build of the kernel (SR)
+// with two k-tiles in flight for launches of up to ptile_sr_max_nt tile columns.  tools/exp_ptile_chain.py shows what bounds
+// 6000 - 12 000 rows: every task first streams the backlog of columns that were final when it was taken, and the chain waits
+// for its own tasks (four re-orderings of the task list measured, none kept).
 #include <cstdlib>
 
 #include "gpk_internal.h"
