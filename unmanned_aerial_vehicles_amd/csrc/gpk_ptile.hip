@@ -87,10 +87,11 @@ constexpr int PROG_OFF = PAUSE_OFF + 1024;    // ctrl ints: per diagonal tile, "
 constexpr int XPROG_OFF = PROG_OFF + 8 * 512; // ctrl ints: per tile row i, "16-column blocks 0 .. v - 1 of tile (i, i - 1) are final"
 constexpr int PT_MAX_FOLLOWERS = 8;           // ... and likewise for the tiles (i, i - 2) .. (i, i - 8): one region of 8 x 512 words per distance
 constexpr int WT_OFF = XPROG_OFF + PT_MAX_FOLLOWERS * 8 * 512;   // ctrl ints: per tile row j of W^T, "tiles (j, j .. j + v - 1) are final" (p.wt)
-// Diagonal task, two schedule choices read off the sub-step stamps (profiles/r05_ptile_substamps.log, r05_ptile_defer_ab.log):
+// Build-time choices of the diagonal task (the A/B builds of profiles/r05_ptile_line_stores_ab.log, r05_ptile_defer_ab.log,
+// r05_ptile_substamps.log set them on the compiler's command line):
 #ifndef PT_LINE_STORES
-#define PT_LINE_STORES 1
-#endif
+#define PT_LINE_STORES 1                      // blocks of L_jj and W_jj^T (and the followers' blocks) leave as whole 128-byte lines; 0: 8-byte stores
+#endif                                        // straight from the accumulators (LML + gradient at N = 1000 0.465 against 0.449 ms)
 #ifndef PT_DEFER
 #define PT_DEFER 1                            // the wave on the factoring wave's SIMD applies the previous block column behind the
 #endif                                        // step's first barrier: the 16 x 16 factor 4612 -> 3552 cycles
