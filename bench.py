@@ -435,9 +435,9 @@ def bench_train(args, be):
     gm = res["gp"].gp_model
     ge = [t for t, g in evals if g]
     gv = [t for t, g in evals if not g]
-    # the optimiser's two runs (start + one restart) execute side by side on two handles / streams (gpr.py: _optimise_from):
-    # an evaluation's own wall time includes its share of waiting for the other run's launches, so the rate is taken over the
-    # whole train_gp(): every gradient evaluation N^3 flops (potrf N^3/3 + inverse factor N^3/3 + W^T W N^3/3),
+    # the optimiser's two runs (start + one restart) execute one after the other at this size (side by side on two handles /
+    # streams up to 7168 rows, where an evaluation's own wall time includes its share of waiting for the other run's launches -
+    # gpr.py: _optimise_from), and the rate is taken over the whole train_gp(): every gradient evaluation N^3 flops (potrf N^3/3 + inverse factor N^3/3 + W^T W N^3/3),
     # every value-only evaluation and the final fit 2 N^3 / 3
     flops = (len(ge) * 1.0 + (len(gv) + args.steps) * 2.0 / 3.0) * float(N) ** 3 / args.steps
     s_train = dt / args.steps
@@ -453,7 +453,7 @@ def bench_train(args, be):
                                "n_restarts_optimizer=1 (src/px4/train_gp_offline.py:124-140, simple_gp.py:156-185)"},
         "lml_grad_evaluations_per_train": len(ge) / args.steps,
         "s_per_lml_grad_evaluation": s_eval,
-        "s_per_lml_grad_evaluation_note": "train_gp() wall time / gradient evaluations (the two optimiser runs overlap)",
+        "s_per_lml_grad_evaluation_note": "train_gp() wall time / gradient evaluations (the optimiser's runs: one after the other above 7168 rows)",
         "s_per_lml_grad_evaluation_own_wall_mean": float(np.mean(ge)), "s_per_lml_grad_evaluation_own_wall_min": float(np.min(ge)),
         "potrf_ms_final_fit": potrf_ms,
         "kernel": str(gm.kernel_), "lml": float(gm.log_marginal_likelihood_value_),

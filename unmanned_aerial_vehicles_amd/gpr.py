@@ -134,8 +134,12 @@ class GaussianProcessRegressor:
         self._L_host = None
         return self
 
-    # the restarts run side by side while all their device models together stay below this many bytes
+    # the restarts run side by side while all their device models together stay below this many bytes ...
     CONCURRENT_RESTART_BYTES = 48e9
+    # ... and while one evaluation leaves most of the chip idle: from ~8000 rows on it fills it and two chains side by side only
+    # take each other's matrix pipe (fit with one restart, side by side / one after the other: N = 6000 244 / 255 ms,
+    # 8000 562 / 555, 10 000 1091 / 1058: profiles/r05_train_restarts_ab.log)
+    CONCURRENT_RESTART_MAX_NP = 7168
 
     def _optimise_from(self, starts, bounds, obj, yn):
         """One optimiser run per start, results in the order of `starts`.  The runs are independent (same data, their own
@@ -144,7 +148,8 @@ class GaussianProcessRegressor:
         chip idle, and two chains interleave.  Same results as one after the other (every run is deterministic)."""
         n = len(starts)
         per_run = 3.3 * self._dev.Np * self._dev.Np * 8.0
-        if n == 1 or not getattr(self, "concurrent_restarts", True) or n * per_run > self.CONCURRENT_RESTART_BYTES:
+        if (n == 1 or not getattr(self, "concurrent_restarts", True) or n * per_run > self.CONCURRENT_RESTART_BYTES
+                or self._dev.Np > self.CONCURRENT_RESTART_MAX_NP):
             return [self._constrained_optimization(obj, t0, bounds) for t0 in starts]
         import torch
         from concurrent.futures import ThreadPoolExecutor
