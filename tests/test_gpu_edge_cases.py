@@ -228,3 +228,28 @@ def test_fast_paths_match_their_plain_forms(monkeypatch):
         (L1, W1, a1, _, m1, v1), (L2, W2, a2, _, m2, v2) = out
         assert relerr(L1, L2) < 1e-13 and relerr(W1, W2) < 1e-11 and relerr(a1, a2) < 1e-10, N
         assert relerr(m1, m2) < 1e-11 and relerr(v1, v2) < 1e-9, N
+
+
+def test_small_launch_build_gives_the_same_evaluation():
+    """The launches of up to 36 tile columns run a second, 256-register build of the one-launch factorisation (two k-tiles in
+    flight in the off-diagonal k-loops, the tiles of the inverse factor included): one LML + gradient evaluation with it and
+    with the 128-register build (ptile_sr = 0) - every task does the same arithmetic in the same order, so the terms, the
+    gradient and alpha are bit-identical."""
+    from unmanned_aerial_vehicles_amd.device import DeviceGP, get_backend
+    be = get_backend(0)
+    rng = np.random.default_rng(11)
+    for N in (1000, 3000):
+        X = rng.standard_normal((N, 7)); Y = np.sin(X @ rng.standard_normal((7, 2))) + 0.1 * rng.standard_normal((N, 2))
+        Y = (Y - Y.mean(0)) / Y.std(0)
+        out = []
+        try:
+            for sr in (1, 0):
+                be.set_options(ptile_sr=sr)
+                dev = DeviceGP(X, Y, be)
+                ld, quad, g = dev.lml_eval(1.3, 1.0, 0.05 + 1e-4, 0.05, True)
+                out.append((ld, np.array(quad), np.array(g), dev.alpha_host()))
+        finally:
+            be.set_options(ptile_sr=1)
+        (ld1, q1, g1, a1), (ld0, q0, g0, a0) = out
+        assert ld1 == ld0 and np.array_equal(q1, q0) and np.array_equal(g1, g0) and np.array_equal(a1, a0), N
+
